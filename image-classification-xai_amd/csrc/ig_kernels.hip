@@ -1,0 +1,332 @@
+// Integrated-Gradients kernels for gfx950 (MI355X): path interpolation (K1), Left-IG cutoff,
+// Riemann accumulation (K2, the roofline kernel), streaming accumulation, IDGI.
+//
+// All of them are HBM-bound element-wise / strided-reduction work: one lane owns a 16-byte
+// column of the image, every wave-instruction moves 1 KiB contiguously, the step loop keeps
+// 8 independent loads in flight per lane, nothing is staged through LDS because no byte is
+// used twice.  Compiled with -ffp-contract=off: products and sums round separately, exactly
+// like the torch expressions they replace.
+#include "xai_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---- tiny vector algebra so that every kernel exists in a float4 and a scalar flavour ----
+template <int W> struct Vec;
+template <> struct Vec<4> {
+  using T = float4;
+  static __device__ __forceinline__ T load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void store(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
+  static __device__ __forceinline__ T splat(float s) { return make_float4(s, s, s, s); }
+};
+template <> struct Vec<1> {
+  using T = float;
+  static __device__ __forceinline__ T load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, T v) { *p = v; }
+  static __device__ __forceinline__ T splat(float s) { return s; }
+};
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 vsub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 vmul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 vdiv(float4 a, float4 b) { return make_float4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+__device__ __forceinline__ float4 vabs(float4 a) { return make_float4(fabsf(a.x), fabsf(a.y), fabsf(a.z), fabsf(a.w)); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float vsub(float a, float b) { return a - b; }
+__device__ __forceinline__ float vmul(float a, float b) { return a * b; }
+__device__ __forceinline__ float vdiv(float a, float b) { return a / b; }
+__device__ __forceinline__ float vabs(float a) { return fabsf(a); }
+
+// =========================================================================== K1 interpolation
+// grid = (element tiles, step chunks, images).  A lane keeps x and (x-b) of its column in
+// registers and writes `steps_per_chunk` rows; alphas come through the scalar cache.
+template <int W>
+__global__ __launch_bounds__(kBlock) void ig_interp_kernel(const float* __restrict__ x, const float* __restrict__ base,
+                                                           float base_scalar, const float* __restrict__ alphas,
+                                                           int64_t alpha_img_stride, int n_alpha, int64_t n_elem,
+                                                           int steps_per_chunk, float* __restrict__ out) {
+  using V = Vec<W>;
+  const int64_t e = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * W;
+  if (e >= n_elem) return;
+  const int img = blockIdx.z;
+  const int s0 = blockIdx.y * steps_per_chunk;
+  const int s1 = min(s0 + steps_per_chunk, n_alpha);
+  const typename V::T xv = V::load(x + img * n_elem + e);
+  const typename V::T bv = base ? V::load(base + img * n_elem + e) : V::splat(base_scalar);
+  const typename V::T dv = vsub(xv, bv);
+  const float* al = alphas + img * alpha_img_stride;
+  float* o = out + (static_cast<int64_t>(img) * n_alpha + s0) * n_elem + e;
+  for (int s = s0; s < s1; ++s, o += n_elem) V::store(o, vadd(bv, vmul(V::splat(al[s]), dv)));
+}
+
+// =========================================================================== Left-IG cutoff
+__global__ __launch_bounds__(kWave) void ig_cutoff_kernel(const float* __restrict__ logits, int n_steps, float alpha_star,
+                                                          int32_t* __restrict__ n_use) {
+  const float* lg = logits + static_cast<int64_t>(blockIdx.x) * n_steps;
+  const int lane = threadIdx.x;
+  float m = -INFINITY;
+  for (int s = lane; s < n_steps; s += kWave) m = fmaxf(m, lg[s]);
+  m = wave_max(m);
+  const float thr = m * alpha_star;
+  int first = INT32_MAX;
+  for (int s = lane; s < n_steps; s += kWave)
+    if (lg[s] > thr) { first = s; break; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, kWave));
+  if (lane == 0) {
+    int cut = (first == INT32_MAX) ? 1 : first;   // nothing above the threshold -> 1
+    if (cut == 0) cut = 1;                        // "avoid rare case where no attribution is returned"
+    n_use[blockIdx.x] = (alpha_star == 1.0f) ? n_steps : cut;
+  }
+}
+
+// =========================================================================== K2 accumulation
+// grid = (pixel tiles, images).  A lane owns W consecutive pixels and walks channel-major
+// through the first n_use step rows: per channel a sequential fp32 sum (s ascending), divided
+// by n_use, times (x - b); the channel sum feeds the optional |.| map.
+template <int W, bool WEIGHTED>
+__global__ __launch_bounds__(kBlock) void ig_accum_kernel(const float* __restrict__ grads, int n_steps,
+                                                          const int32_t* __restrict__ n_use_dev, int n_use_host,
+                                                          const float* __restrict__ w1, const float* __restrict__ w2,
+                                                          const float* __restrict__ x, const float* __restrict__ base,
+                                                          float base_scalar, int C, int64_t hw,
+                                                          float* __restrict__ out, float* __restrict__ out_abs) {
+  using V = Vec<W>;
+  using T = typename V::T;
+  constexpr int U = 8;
+  const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * W;
+  if (p >= hw) return;
+  const int img = blockIdx.y;
+  int n_use = n_use_dev ? n_use_dev[img] : n_use_host;
+  n_use = max(1, min(n_use, n_steps));
+  const T denom = V::splat(static_cast<float>(WEIGHTED ? n_steps : n_use));
+  const int64_t row = static_cast<int64_t>(C) * hw;               // floats between two steps
+  const float* gi = grads + static_cast<int64_t>(img) * n_steps * row + p;
+  const float* wa = WEIGHTED ? w1 + static_cast<int64_t>(img) * n_steps : nullptr;
+  const float* wb = (WEIGHTED && w2) ? w2 + static_cast<int64_t>(img) * n_steps : nullptr;
+  T tot = V::splat(0.f);
+  for (int c = 0; c < C; ++c) {
+    const float* g = gi + c * hw;
+    T acc = V::splat(0.f);
+    int s = 0;
+    for (; s + U <= n_use; s += U) {
+      T v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = V::load(g + (s + u) * row);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (WEIGHTED) {
+          v[u] = vmul(v[u], V::splat(wa[s + u]));
+          if (wb) v[u] = vmul(v[u], V::splat(wb[s + u]));
+        }
+        acc = vadd(acc, v[u]);
+      }
+    }
+    for (; s < n_use; ++s) {
+      T v = V::load(g + s * row);
+      if (WEIGHTED) {
+        v = vmul(v, V::splat(wa[s]));
+        if (wb) v = vmul(v, V::splat(wb[s]));
+      }
+      acc = vadd(acc, v);
+    }
+    const int64_t at = (static_cast<int64_t>(img) * C + c) * hw + p;
+    const T bv = base ? V::load(base + at) : V::splat(base_scalar);
+    const T o = vmul(vdiv(acc, denom), vsub(V::load(x + at), bv));
+    V::store(out + at, o);
+    tot = vadd(tot, o);
+  }
+  if (out_abs) V::store(out_abs + static_cast<int64_t>(img) * hw + p, vabs(tot));
+}
+
+// streaming form: acc += sum over the batch rows
+template <int W>
+__global__ __launch_bounds__(kBlock) void ig_accum_add_kernel(const float* __restrict__ grads, int n_batch,
+                                                              float* __restrict__ acc, int64_t n_elem) {
+  using V = Vec<W>;
+  using T = typename V::T;
+  constexpr int U = 8;
+  const int64_t e = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * W;
+  if (e >= n_elem) return;
+  const float* g = grads + e;
+  T a = V::load(acc + e);
+  int b = 0;
+  for (; b + U <= n_batch; b += U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = V::load(g + (b + u) * n_elem);
+#pragma unroll
+    for (int u = 0; u < U; ++u) a = vadd(a, v[u]);
+  }
+  for (; b < n_batch; ++b) a = vadd(a, V::load(g + b * n_elem));
+  V::store(acc + e, a);
+}
+
+template <int W>
+__global__ __launch_bounds__(kBlock) void ig_finish_kernel(const float* __restrict__ acc, int n_steps,
+                                                           const float* __restrict__ x, const float* __restrict__ base,
+                                                           float base_scalar, int C, int64_t hw, float* __restrict__ out,
+                                                           float* __restrict__ out_abs) {
+  using V = Vec<W>;
+  using T = typename V::T;
+  const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * W;
+  if (p >= hw) return;
+  const int img = blockIdx.y;
+  const T denom = V::splat(static_cast<float>(n_steps));
+  T tot = V::splat(0.f);
+  for (int c = 0; c < C; ++c) {
+    const int64_t at = (static_cast<int64_t>(img) * C + c) * hw + p;
+    const T bv = base ? V::load(base + at) : V::splat(base_scalar);
+    const T o = vmul(vdiv(V::load(acc + at), denom), vsub(V::load(x + at), bv));
+    V::store(out + at, o);
+    tot = vadd(tot, o);
+  }
+  if (out_abs) V::store(out_abs + static_cast<int64_t>(img) * hw + p, vabs(tot));
+}
+
+// =========================================================================== IDGI
+// one 1024-thread workgroup per row: lane-strided float4 loads, fp32 partials, wave shuffle
+// reduce, 16 wave partials through LDS -- a fixed tree, so the result is reproducible.
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* __restrict__ g, int64_t n_elem, float* __restrict__ out) {
+  __shared__ float part[16];
+  const float* row = g + static_cast<int64_t>(blockIdx.x) * n_elem;
+  float acc = 0.f;
+  const bool vec = ((n_elem & 3) == 0) && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+  if (vec) {
+    for (int64_t i = threadIdx.x * 4; i < n_elem; i += 1024 * 4) {
+      const float4 v = ld4(row + i);
+      acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < n_elem; i += 1024) acc += row[i] * row[i];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float v = threadIdx.x < 16 ? part[threadIdx.x] : 0.f;
+    v = wave_sum(v);
+    if (threadIdx.x == 0) out[blockIdx.x] = v;
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(kBlock) void idgi_accum_kernel(const float* __restrict__ grads, int n_steps,
+                                                            const float* __restrict__ logits, const float* __restrict__ sumsq,
+                                                            int64_t n_elem, float* __restrict__ out) {
+  using V = Vec<W>;
+  using T = typename V::T;
+  const int64_t e = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * W;
+  if (e >= n_elem) return;
+  T acc = V::splat(0.f);
+  for (int s = 0; s + 1 < n_steps; ++s) {
+    const T g = V::load(grads + s * n_elem + e);
+    const float d = logits[s + 1] - logits[s];
+    acc = vadd(acc, vdiv(vmul(vmul(g, g), V::splat(d)), V::splat(sumsq[s])));
+  }
+  V::store(out + e, acc);
+}
+
+inline bool can_vec4(int64_t n, std::initializer_list<const void*> ptrs) {
+  if (n & 3) return false;
+  for (const void* p : ptrs)
+    if (p && !xai_aligned16(p)) return false;
+  return true;
+}
+
+}  // namespace
+
+// ============================================================================== C ABI
+XAI_EXPORT int xai_ig_interp_f32(const float* x, const float* baseline, float baseline_scalar, const float* alphas,
+                                 int64_t alpha_img_stride, int n_img, int n_alpha, int64_t n_elem, float* out,
+                                 xai_stream_t stream) {
+  XAI_REQUIRE_PTR(x); XAI_REQUIRE_PTR(alphas); XAI_REQUIRE_PTR(out);
+  XAI_REQUIRE(n_img > 0 && n_alpha > 0 && n_elem > 0 && alpha_img_stride >= 0, XAI_E_SHAPE);
+  XAI_REQUIRE(n_img <= 65535, XAI_E_UNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // enough step chunks that even one image fills the chip (>= ~1000 workgroups)
+  const bool vec = can_vec4(n_elem, {x, baseline, out});
+  const int64_t tiles = xai_ceil_div(n_elem, kBlock * (vec ? 4 : 1));
+  int chunks = static_cast<int>(std::min<int64_t>(n_alpha, std::max<int64_t>(1, xai_ceil_div(2048, tiles * n_img))));
+  const int per = static_cast<int>(xai_ceil_div(n_alpha, chunks));
+  chunks = static_cast<int>(xai_ceil_div(n_alpha, per));
+  dim3 grid(static_cast<unsigned>(tiles), chunks, n_img);
+  if (vec)
+    hipLaunchKernelGGL(ig_interp_kernel<4>, grid, dim3(kBlock), 0, st, x, baseline, baseline_scalar, alphas, alpha_img_stride, n_alpha, n_elem, per, out);
+  else
+    hipLaunchKernelGGL(ig_interp_kernel<1>, grid, dim3(kBlock), 0, st, x, baseline, baseline_scalar, alphas, alpha_img_stride, n_alpha, n_elem, per, out);
+  return xai_launch_status();
+}
+
+XAI_EXPORT int xai_ig_cutoff_f32(const float* logits, int n_img, int n_steps, float alpha_star, int32_t* n_use,
+                                 xai_stream_t stream) {
+  XAI_REQUIRE_PTR(logits); XAI_REQUIRE_PTR(n_use);
+  XAI_REQUIRE(n_img > 0 && n_steps > 0, XAI_E_SHAPE);
+  hipLaunchKernelGGL(ig_cutoff_kernel, dim3(n_img), dim3(kWave), 0, static_cast<hipStream_t>(stream), logits, n_steps, alpha_star, n_use);
+  return xai_launch_status();
+}
+
+XAI_EXPORT int xai_ig_accum_f32(const float* grads, int n_img, int n_steps, const int32_t* n_use_dev, int n_use_host,
+                                const float* step_w1, const float* step_w2, const float* x, const float* baseline,
+                                float baseline_scalar, int C, int64_t hw, float* out_chw, float* out_abs_hw,
+                                xai_stream_t stream) {
+  XAI_REQUIRE_PTR(grads); XAI_REQUIRE_PTR(x); XAI_REQUIRE_PTR(out_chw);
+  XAI_REQUIRE(n_img > 0 && n_steps > 0 && C > 0 && hw > 0, XAI_E_SHAPE);
+  XAI_REQUIRE(n_use_dev != nullptr || (n_use_host >= 1 && n_use_host <= n_steps), XAI_E_SHAPE);
+  XAI_REQUIRE(step_w1 != nullptr || step_w2 == nullptr, XAI_E_SHAPE);
+  XAI_REQUIRE(n_img <= 65535, XAI_E_UNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = can_vec4(hw, {grads, x, baseline, out_chw, out_abs_hw});
+  dim3 grid(static_cast<unsigned>(xai_ceil_div(hw, kBlock * (vec ? 4 : 1))), n_img);
+#define XAI_ACCUM(W, WT) \
+  hipLaunchKernelGGL((ig_accum_kernel<W, WT>), grid, dim3(kBlock), 0, st, grads, n_steps, n_use_dev, n_use_host, step_w1, \
+                     step_w2, x, baseline, baseline_scalar, C, hw, out_chw, out_abs_hw)
+  if (vec) { if (step_w1) XAI_ACCUM(4, true); else XAI_ACCUM(4, false); }
+  else     { if (step_w1) XAI_ACCUM(1, true); else XAI_ACCUM(1, false); }
+#undef XAI_ACCUM
+  return xai_launch_status();
+}
+
+XAI_EXPORT int xai_ig_accum_add_f32(const float* grads, int n_batch, float* acc, int64_t n_elem, xai_stream_t stream) {
+  XAI_REQUIRE_PTR(grads); XAI_REQUIRE_PTR(acc);
+  XAI_REQUIRE(n_batch > 0 && n_elem > 0, XAI_E_SHAPE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = can_vec4(n_elem, {grads, acc});
+  dim3 grid(static_cast<unsigned>(xai_ceil_div(n_elem, kBlock * (vec ? 4 : 1))));
+  if (vec) hipLaunchKernelGGL(ig_accum_add_kernel<4>, grid, dim3(kBlock), 0, st, grads, n_batch, acc, n_elem);
+  else     hipLaunchKernelGGL(ig_accum_add_kernel<1>, grid, dim3(kBlock), 0, st, grads, n_batch, acc, n_elem);
+  return xai_launch_status();
+}
+
+XAI_EXPORT int xai_ig_finish_f32(const float* acc, int n_img, int n_steps, const float* x, const float* baseline,
+                                 float baseline_scalar, int C, int64_t hw, float* out_chw, float* out_abs_hw,
+                                 xai_stream_t stream) {
+  XAI_REQUIRE_PTR(acc); XAI_REQUIRE_PTR(x); XAI_REQUIRE_PTR(out_chw);
+  XAI_REQUIRE(n_img > 0 && n_steps > 0 && C > 0 && hw > 0, XAI_E_SHAPE);
+  XAI_REQUIRE(n_img <= 65535, XAI_E_UNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = can_vec4(hw, {acc, x, baseline, out_chw, out_abs_hw});
+  dim3 grid(static_cast<unsigned>(xai_ceil_div(hw, kBlock * (vec ? 4 : 1))), n_img);
+  if (vec) hipLaunchKernelGGL(ig_finish_kernel<4>, grid, dim3(kBlock), 0, st, acc, n_steps, x, baseline, baseline_scalar, C, hw, out_chw, out_abs_hw);
+  else     hipLaunchKernelGGL(ig_finish_kernel<1>, grid, dim3(kBlock), 0, st, acc, n_steps, x, baseline, baseline_scalar, C, hw, out_chw, out_abs_hw);
+  return xai_launch_status();
+}
+
+XAI_EXPORT int xai_sumsq_f32(const float* grads, int n_rows, int64_t n_elem, float* sumsq, xai_stream_t stream) {
+  XAI_REQUIRE_PTR(grads); XAI_REQUIRE_PTR(sumsq);
+  XAI_REQUIRE(n_rows > 0 && n_elem > 0, XAI_E_SHAPE);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(n_rows), dim3(1024), 0, static_cast<hipStream_t>(stream), grads, n_elem, sumsq);
+  return xai_launch_status();
+}
+
+XAI_EXPORT int xai_idgi_accum_f32(const float* grads, int n_steps, const float* logits, const float* sumsq,
+                                  int64_t n_elem, float* out, xai_stream_t stream) {
+  XAI_REQUIRE_PTR(grads); XAI_REQUIRE_PTR(logits); XAI_REQUIRE_PTR(sumsq); XAI_REQUIRE_PTR(out);
+  XAI_REQUIRE(n_steps > 1 && n_elem > 0, XAI_E_SHAPE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = can_vec4(n_elem, {grads, out});
+  dim3 grid(static_cast<unsigned>(xai_ceil_div(n_elem, kBlock * (vec ? 4 : 1))));
+  if (vec) hipLaunchKernelGGL(idgi_accum_kernel<4>, grid, dim3(kBlock), 0, st, grads, n_steps, logits, sumsq, n_elem, out);
+  else     hipLaunchKernelGGL(idgi_accum_kernel<1>, grid, dim3(kBlock), 0, st, grads, n_steps, logits, sumsq, n_elem, out);
+  return xai_launch_status();
+}

@@ -1,0 +1,180 @@
+// K4/K5: RISE random-mask application and score-weighted accumulation for gfx950.
+//
+// A mask is never read from memory: it is the order-1 ("bilinear", mirror boundary,
+// half-pixel grid) up-sampling of an s x s binary grid to (s+1)*cell, cropped at a per-mask
+// shift -- scipy.ndimage.zoom(grid, up/s, order=1, mode='mirror', grid_mode=True), which is
+// what skimage.transform.resize(order=1, mode='reflect') runs.  Tap positions/weights are
+// computed in fp64 (they are exact-to-fp32 then), the 4-tap blend in fp32.
+//
+// K4 (write-bound, C*H*W*4 B per mask): grid = (pixel tiles, masks); the mask's s*s grid
+//    bytes sit in LDS, a lane produces 4 pixels x C channels with 16-byte stores.
+// K5 (compute/LDS-bound, almost no HBM traffic): grid = (pixel tiles, mask slices); tap tables
+//    for every up-sampled row/column live in LDS, mask grids are staged in LDS 256 at a time,
+//    a lane owns one pixel and accumulates score*mask in fp64; one fp64 atomic per pixel per
+//    slice merges the slices.
+#include "xai_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Tap { int i0, i1; float t; };
+
+// value(j) = (1-t)*g[i0] + t*g[i1] for output index j of an n_in -> n_out up-sampling
+__device__ __forceinline__ Tap make_tap(int j, int n_in, int n_out) {
+  double c = (j + 0.5) * (static_cast<double>(n_in) / static_cast<double>(n_out)) - 0.5;
+  if (c < 0) c = -c;                                   // mirror about sample 0
+  const int i0 = static_cast<int>(floor(c));
+  int i1 = i0 + 1;
+  if (i1 >= n_in) i1 = 2 * n_in - 2 - i1;              // mirror about sample n_in-1
+  if (i1 < 0) i1 = 0;                                  // n_in == 1
+  return Tap{i0, i1, static_cast<float>(c - i0)};
+}
+
+__device__ __forceinline__ float blend(const uint8_t* g, int s, const Tap& r, const Tap& c) {
+  const float wr0 = 1.f - r.t, wr1 = r.t, wc0 = 1.f - c.t, wc1 = c.t;
+  float v = g[r.i0 * s + c.i0] ? wr0 * wc0 : 0.f;
+  v += g[r.i0 * s + c.i1] ? wr0 * wc1 : 0.f;
+  v += g[r.i1 * s + c.i0] ? wr1 * wc0 : 0.f;
+  v += g[r.i1 * s + c.i1] ? wr1 * wc1 : 0.f;
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void rise_apply_kernel(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift, int s,
+                                                            int cell_h, int cell_w, const float* __restrict__ image, int C, int H,
+                                                            int W, float* __restrict__ masked, float* __restrict__ masks) {
+  extern __shared__ uint8_t g[];                        // [s][s]
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < s * s; i += kBlock) g[i] = grid[static_cast<int64_t>(n) * s * s + i];
+  __syncthreads();
+  const int64_t hw = static_cast<int64_t>(H) * W;
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= hw) return;
+  const int y = static_cast<int>(p / W), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
+  const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
+  const Tap tr = make_tap(y + shift[2 * n], s, up_h);
+  const Tap tc = make_tap(x + shift[2 * n + 1], s, up_w);
+  const float m = blend(g, s, tr, tc);
+  if (masks) masks[static_cast<int64_t>(n) * hw + p] = m;
+  if (masked) {
+    float* o = masked + static_cast<int64_t>(n) * C * hw + p;
+    for (int c = 0; c < C; ++c) o[c * hw] = image[c * hw + p] * m;
+  }
+}
+
+// 4 pixels per lane along x (W % 4 == 0, 16-byte aligned planes)
+__global__ __launch_bounds__(kBlock) void rise_apply_kernel_v4(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
+                                                               int s, int cell_h, int cell_w, const float* __restrict__ image, int C,
+                                                               int H, int W, float* __restrict__ masked, float* __restrict__ masks) {
+  extern __shared__ uint8_t g[];
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < s * s; i += kBlock) g[i] = grid[static_cast<int64_t>(n) * s * s + i];
+  __syncthreads();
+  const int64_t hw = static_cast<int64_t>(H) * W;
+  const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
+  if (p >= hw) return;
+  const int y = static_cast<int>(p / W), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
+  const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
+  const int sx = shift[2 * n + 1];
+  const Tap tr = make_tap(y + shift[2 * n], s, up_h);
+  float4 m;
+  m.x = blend(g, s, tr, make_tap(x + sx, s, up_w));
+  m.y = blend(g, s, tr, make_tap(x + 1 + sx, s, up_w));
+  m.z = blend(g, s, tr, make_tap(x + 2 + sx, s, up_w));
+  m.w = blend(g, s, tr, make_tap(x + 3 + sx, s, up_w));
+  if (masks) st4(masks + static_cast<int64_t>(n) * hw + p, m);
+  if (masked) {
+    float* o = masked + static_cast<int64_t>(n) * C * hw + p;
+    for (int c = 0; c < C; ++c) {
+      const float4 v = ld4(image + c * hw + p);
+      st4(o + c * hw, make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w));
+    }
+  }
+}
+
+constexpr int kStage = 256;   // masks staged in LDS per round
+
+__global__ __launch_bounds__(kBlock) void rise_accum_kernel(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
+                                                            const float* __restrict__ scores, int n_masks, int per_slice, int s,
+                                                            int cell_h, int cell_w, int H, int W, double scale,
+                                                            double* __restrict__ acc_out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
+  Tap* rtap = reinterpret_cast<Tap*>(lds_raw);                      // [up_h]
+  Tap* ctap = rtap + up_h;                                          // [up_w]
+  float* sc = reinterpret_cast<float*>(ctap + up_w);                // [kStage]
+  int* sh = reinterpret_cast<int*>(sc + kStage);                    // [kStage][2]
+  uint8_t* gs = reinterpret_cast<uint8_t*>(sh + 2 * kStage);        // [kStage][s*s]
+  for (int i = threadIdx.x; i < up_h; i += kBlock) rtap[i] = make_tap(i, s, up_h);
+  for (int i = threadIdx.x; i < up_w; i += kBlock) ctap[i] = make_tap(i, s, up_w);
+  const int64_t hw = static_cast<int64_t>(H) * W;
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool live = p < hw;
+  const int y = live ? static_cast<int>(p / W) : 0, x = live ? static_cast<int>(p - static_cast<int64_t>(y) * W) : 0;
+  const int n_lo = blockIdx.y * per_slice, n_hi = min(n_lo + per_slice, n_masks);
+  const int ss = s * s;
+  double acc = 0.0;
+  for (int base = n_lo; base < n_hi; base += kStage) {
+    const int cnt = min(kStage, n_hi - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += kBlock) {
+      sc[i] = scores[base + i];
+      sh[2 * i] = shift[2 * (base + i)];
+      sh[2 * i + 1] = shift[2 * (base + i) + 1];
+    }
+    for (int i = threadIdx.x; i < cnt * ss; i += kBlock) gs[i] = grid[static_cast<int64_t>(base) * ss + i];
+    __syncthreads();
+    if (live) {
+      for (int m = 0; m < cnt; ++m) {
+        const Tap tr = rtap[y + sh[2 * m]];
+        const Tap tc = ctap[x + sh[2 * m + 1]];
+        acc += static_cast<double>(sc[m]) * static_cast<double>(blend(gs + m * ss, s, tr, tc));
+      }
+    }
+  }
+  if (live) atomicAdd(acc_out + p, acc * scale);
+}
+
+}  // namespace
+
+XAI_EXPORT int xai_rise_apply_f32(const uint8_t* grid, const int32_t* shift, int n_masks, int s, int cell_h, int cell_w,
+                                  const float* image, int C, int H, int W, float* masked_out, float* masks_out,
+                                  xai_stream_t stream) {
+  XAI_REQUIRE_PTR(grid); XAI_REQUIRE_PTR(shift);
+  XAI_REQUIRE(masked_out != nullptr || masks_out != nullptr, XAI_E_NULL);
+  XAI_REQUIRE(masked_out == nullptr || image != nullptr, XAI_E_NULL);
+  XAI_REQUIRE(n_masks > 0 && s > 0 && cell_h > 0 && cell_w > 0 && C > 0 && H > 0 && W > 0, XAI_E_SHAPE);
+  XAI_REQUIRE(H + cell_h - 1 <= (s + 1) * cell_h && W + cell_w - 1 <= (s + 1) * cell_w, XAI_E_SHAPE);   // crop stays inside
+  XAI_REQUIRE(s <= 64 && n_masks <= 65535, XAI_E_UNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t hw = static_cast<int64_t>(H) * W;
+  const bool vec = (W % 4 == 0) && xai_aligned16(image) && xai_aligned16(masked_out) && xai_aligned16(masks_out);
+  if (vec) {
+    dim3 g(static_cast<unsigned>(xai_ceil_div(hw, kBlock * 4)), n_masks);
+    hipLaunchKernelGGL(rise_apply_kernel_v4, g, dim3(kBlock), s * s, st, grid, shift, s, cell_h, cell_w, image, C, H, W, masked_out, masks_out);
+  } else {
+    dim3 g(static_cast<unsigned>(xai_ceil_div(hw, kBlock)), n_masks);
+    hipLaunchKernelGGL(rise_apply_kernel, g, dim3(kBlock), s * s, st, grid, shift, s, cell_h, cell_w, image, C, H, W, masked_out, masks_out);
+  }
+  return xai_launch_status();
+}
+
+XAI_EXPORT int xai_rise_accum_f64(const uint8_t* grid, const int32_t* shift, const float* scores, int n_masks, int s, int cell_h,
+                                  int cell_w, int H, int W, double scale, double* acc, xai_stream_t stream) {
+  XAI_REQUIRE_PTR(grid); XAI_REQUIRE_PTR(shift); XAI_REQUIRE_PTR(scores); XAI_REQUIRE_PTR(acc);
+  XAI_REQUIRE(n_masks > 0 && s > 0 && cell_h > 0 && cell_w > 0 && H > 0 && W > 0, XAI_E_SHAPE);
+  XAI_REQUIRE(H + cell_h - 1 <= (s + 1) * cell_h && W + cell_w - 1 <= (s + 1) * cell_w, XAI_E_SHAPE);
+  const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
+  const size_t lds = static_cast<size_t>(up_h + up_w) * sizeof(Tap) + kStage * (sizeof(float) + 2 * sizeof(int)) +
+                     static_cast<size_t>(kStage) * s * s;
+  XAI_REQUIRE(s <= 64 && lds <= 64 * 1024, XAI_E_UNSUPPORTED);
+  const int64_t hw = static_cast<int64_t>(H) * W;
+  const int64_t tiles = xai_ceil_div(hw, kBlock);
+  int slices = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(xai_ceil_div(n_masks, 64), xai_ceil_div(2048, tiles))));
+  const int per = static_cast<int>(xai_ceil_div(n_masks, slices));
+  slices = static_cast<int>(xai_ceil_div(n_masks, per));
+  dim3 g(static_cast<unsigned>(tiles), slices);
+  hipLaunchKernelGGL(rise_accum_kernel, g, dim3(kBlock), lds, static_cast<hipStream_t>(stream), grid, shift, scores, n_masks, per, s,
+                     cell_h, cell_w, H, W, scale, acc);
+  return xai_launch_status();
+}

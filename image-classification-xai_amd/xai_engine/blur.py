@@ -1,0 +1,40 @@
+"""Gaussian-blur substrate: the reference's `gkern` (host, scipy) and a device-side separable
+application of it (K7) to use as `substrate_fn`."""
+import numpy as np
+import torch
+from scipy.ndimage import gaussian_filter
+
+from . import kernels as K
+from .ig import hip_device
+
+
+def gkern(klen, nsig):
+    """(3,3,klen,klen) float32 CPU tensor: scipy-smoothed dirac on the channel diagonal
+    (reference MASTestFunctions.py:11-28).  A klen x klen host computation done once."""
+    d = np.zeros((klen, klen))
+    d[klen // 2, klen // 2] = 1
+    k = gaussian_filter(d, nsig)
+    kern = np.zeros((3, 3, klen, klen))
+    kern[0, 0] = kern[1, 1] = kern[2, 2] = k
+    return torch.from_numpy(kern.astype('float32'))
+
+
+def gkern1d(klen, nsig):
+    """1-D factor v of gkern: gkern[c,c] = outer(v, v) (scipy filters axis by axis)."""
+    d = np.zeros(klen)
+    d[klen // 2] = 1
+    return torch.from_numpy(gaussian_filter(d, nsig).astype('float32'))
+
+
+class GaussianBlur:
+    """substrate_fn for the insertion metrics: zero-padded blur with gkern(klen, nsig), computed
+    on `device` by the separable HIP kernel.  Accepts a CPU or device (B,C,H,W) tensor and
+    returns a device tensor.  Equivalent of `lambda x: conv2d(x, gkern(klen, nsig),
+    padding=klen//2)` (reference evaluatePerturbation.py:456-459)."""
+
+    def __init__(self, klen, nsig, device):
+        self.device = hip_device(device)
+        self.k1d = gkern1d(klen, nsig).to(self.device)
+
+    def __call__(self, x):
+        return K.blur_sep(x.to(self.device, torch.float32).contiguous(), self.k1d)

@@ -1,0 +1,59 @@
+"""Grad-CAM on the HIP kernels, behind captum's `LayerGradCam` call shape.
+
+The reference calls captum 0.7.0 (evaluatePerturbation.py:147-153):
+    LayerGradCam(model, model.layer4).attribute(x, target, relu_attributions=True)   # (1,1,7,7)
+then torchvision Resize -> x ones(3,H,W) -> |sum over channels| (:153,:181).  The layer forward
+and the backward to the layer stay PyTorch-ROCm; the channel-weighted reduction and the
+up-sample are xai_gradcam_f32 / xai_bilinear_up_f32.
+"""
+import torch
+
+from . import kernels as K
+from ._lib import XaiHipError
+
+
+class LayerGradCam:
+    def __init__(self, forward_func, layer, device_ids=None):
+        self.forward_func = forward_func
+        self.layer = layer
+
+    def _act_and_grad(self, inputs, target):
+        kept = {}
+        handle = self.layer.register_forward_hook(lambda mod, inp, out: kept.__setitem__("act", out))
+        try:
+            with torch.enable_grad():
+                if not inputs.requires_grad:        # captum's apply_gradient_requirements: the layer output
+                    inputs = inputs.detach().requires_grad_(True)   # needs a graph even with frozen weights
+                out = self.forward_func(inputs)
+                out = out if isinstance(out, torch.Tensor) else out.logits
+                if target is None:
+                    score = out.sum()
+                elif torch.is_tensor(target) and target.dim() > 0 and target.numel() == out.shape[0] and out.shape[0] > 1:
+                    score = out.gather(1, target.reshape(-1, 1).to(out.device)).sum()
+                else:
+                    score = out[:, int(target)].sum()
+                (grad,) = torch.autograd.grad(score, kept["act"])
+        finally:
+            handle.remove()
+        return kept["act"].detach(), grad.detach()
+
+    def attribute(self, inputs, target=None, additional_forward_args=None, attribute_to_layer_input=False,
+                  relu_attributions=False, attr_dim_summation=True):
+        """-> (B,1,h,w) like captum: mean-over-space gradient weights, weighted channel sum, optional ReLU."""
+        if additional_forward_args is not None or attribute_to_layer_input or not attr_dim_summation:
+            raise NotImplementedError("only the call shape used by the reference harness is accelerated")
+        if not inputs.is_cuda:
+            raise XaiHipError("LayerGradCam.attribute needs its input on a HIP device ('cuda:N')")
+        act, grad = self._act_and_grad(inputs, target)
+        if act.dim() != 4:
+            raise NotImplementedError("layer output must be (B,C,h,w)")
+        cam = K.gradcam(act.float().contiguous(), grad.float().contiguous(), relu=relu_attributions)
+        return cam.unsqueeze(1)
+
+
+def gradcam_saliency(model, layer, inputs, target, out_hw, channels=3):
+    """The (B,H,W) map get_CNN_attr produces for "gc": |sum of `channels` copies of the
+    up-sampled, ReLU'd cam| (reference evaluatePerturbation.py:147-153,181), fused into the
+    up-sample kernel as scale = channels, take_abs."""
+    cam = LayerGradCam(model, layer).attribute(inputs, target, relu_attributions=True)
+    return K.bilinear_up(cam[:, 0].contiguous(), out_hw[0], out_hw[1], scale=float(channels), take_abs=True)

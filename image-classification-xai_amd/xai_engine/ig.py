@@ -1,0 +1,204 @@
+"""Integrated-Gradients family on the HIP kernels.
+
+The classifier forward/backward stays PyTorch-ROCm (`getGradientsParallel`); the path
+interpolation, the Left-IG cutoff and the Riemann accumulation run in libxai_hip.so.
+Mirrors util/attribution_methods/saliencyMethods.py of the reference (signatures, return
+shapes, the print-and-return-zeros error convention); `ig_batch` is the multi-image fast
+path the reference does not have.
+"""
+import torch
+
+from . import kernels as K
+from ._lib import XaiHipError
+
+
+def hip_device(device):
+    """'cuda:N' / torch.device -> torch.device on a HIP GPU; anything else raises: the
+    product has no CPU path."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise XaiHipError(f"device '{device}' is not a HIP GPU: xai_engine runs on 'cuda:N' (ROCm) only")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def _logits_of(output):
+    return output if isinstance(output, torch.Tensor) else output.logits
+
+
+def getGradientsParallel(inputs, model, target_class):
+    """d logit[target] / d inputs for a batch; raw logits (reference saliencyMethods.py:209-215)."""
+    output = _logits_of(model(inputs))
+    scores = output[:, target_class]
+    gradients = torch.autograd.grad(scores, inputs, grad_outputs=torch.ones_like(scores))[0]
+    return gradients.detach().squeeze(), scores.detach().squeeze()
+
+
+def getPredictionParallel(inputs, model, target_class):
+    """(reference saliencyMethods.py:218-224)"""
+    output = _logits_of(model(inputs))
+    return output[:, target_class].detach().squeeze()
+
+
+def input_grad(input, model, target_class):
+    """(reference saliencyMethods.py:7-11)"""
+    input.requires_grad = True
+    gradient, _ = getGradientsParallel(input, model, target_class)
+    input.requires_grad = False
+    return gradient
+
+
+def _prep(input, baseline, device):
+    dev = hip_device(device)
+    x = input.to(dev, torch.float32).contiguous()
+    if torch.is_tensor(baseline):
+        base = baseline.to(dev, torch.float32).contiguous()
+        if base.shape != x.shape:
+            base = base.expand_as(x).contiguous()
+    else:
+        base = float(baseline)
+    return dev, x, base
+
+
+def _path(x, base, alphas, model, batch_size, target_class, want_grads=True):
+    """Walk the path in `batch_size` chunks.  x: (1,C,H,W); alphas: (steps,) on the device.
+    Returns grads (1, steps, C,H,W) (or None) and logits (1, steps)."""
+    steps = alphas.shape[0]
+    dev = x.device
+    grads = torch.empty((1, steps) + tuple(x.shape[1:]), dtype=torch.float32, device=dev) if want_grads else None
+    logits = torch.empty((1, steps), dtype=torch.float32, device=dev)
+    for lo in range(0, steps, batch_size):
+        hi = lo + batch_size
+        imgs = K.ig_interp(x, base, alphas[lo:hi])[0]                    # (batch, C,H,W), a fresh leaf
+        if want_grads:
+            imgs.requires_grad_(True)
+            g, s = getGradientsParallel(imgs, model, target_class)
+            grads[0, lo:hi] = g.reshape(grads[0, lo:hi].shape)
+        else:
+            with torch.no_grad():
+                s = getPredictionParallel(imgs, model, target_class)
+        logits[0, lo:hi] = s.reshape(-1)
+    return grads, logits
+
+
+def IG(input, model, steps, batch_size, alpha_star, baseline, device, target_class):
+    """IG (alpha_star == 1) / Left-IG of one image (1,C,H,W) -> (C,H,W) on the device
+    (reference saliencyMethods.py:13-72)."""
+    if steps % batch_size != 0:
+        print("steps must be evenly divisible by batch size: " + str(batch_size) + "!")
+        return 0, 0, 0, 0
+    dev, x, base = _prep(input, baseline, device)
+    alphas = torch.linspace(0, 1, steps).to(dev)          # computed on the host, as the reference does
+    grads, logits = _path(x, base, alphas, model, batch_size, target_class)
+    n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)
+    return K.ig_accum(grads, x, base, n_use=n_use)[0]
+
+
+def getSlopes(baseline, baseline_diff, model, steps, batch_size, device, target_class):
+    """Finite-difference logit slopes on the uniform path (reference saliencyMethods.py:226-261).
+    Takes baseline and (input - baseline) like the reference."""
+    if steps % batch_size != 0:
+        print("steps must be evenly divisible by batch size: " + str(batch_size) + "!")
+        return 0, 0
+    dev = hip_device(device)
+    base = baseline.to(dev, torch.float32).contiguous()
+    x = (base + baseline_diff.to(dev, torch.float32)).contiguous()
+    cpu_alphas = torch.linspace(0, 1, steps)
+    _, logits = _path(x, base, cpu_alphas.to(dev), model, batch_size, target_class, want_grads=False)
+    x_diff = float(cpu_alphas[1] - cpu_alphas[0])
+    # 50 numbers: finish on the host so the division is the IEEE one the reference's CPU path
+    # performs (a device tensor / python scalar is a multiply by the reciprocal)
+    lg = logits[0].cpu()
+    slopes = torch.zeros(steps)
+    slopes[1:] = (lg[1:] - lg[:-1]) / x_diff
+    return slopes.to(dev), x_diff
+
+
+def getAlphaParameters(slopes, steps, step_size):
+    """IDG's slope-proportional sample placement (reference saliencyMethods.py:264-314):
+    a 50-element host computation, returned as CPU tensors like the reference."""
+    s = slopes.detach().float().cpu()
+    unit = (s - s.min()) / (s.max() - s.min())
+    unit[0] = 0
+    share = unit / unit.sum()
+    want = share * steps
+    count = want.type(torch.int)
+    spare = steps - int(count.sum())
+    want[torch.where(count != 0)[0]] = -1
+    by_need = torch.flip(torch.sort(want)[1], dims=[0])
+    count[by_need[0:spare]] = 1
+    alphas = torch.zeros(steps)
+    substep = torch.zeros(steps)
+    at, a0 = 0, 0
+    for n in count:
+        n = int(n)
+        if n == 0:
+            continue
+        alphas[at:at + n] = torch.linspace(a0, a0 + step_size, n + 1)[0:n]
+        substep[at:at + n] = step_size / n
+        at += n
+        a0 += step_size
+    return alphas, substep
+
+
+def IDG(input, model, steps, batch_size, baseline, device, target_class):
+    """Integrated Decision Gradients (reference saliencyMethods.py:74-136)."""
+    if batch_size == 0 or steps % batch_size != 0:
+        print("steps must be evenly divisible by batch size!")
+        return 0, 0, 0
+    dev, x, base = _prep(input, baseline, device)
+    base_t = base if torch.is_tensor(base) else torch.full_like(x, base)
+    slopes, step_size = getSlopes(base_t, x - base_t, model, steps, batch_size, dev, target_class)
+    alphas, substep = getAlphaParameters(slopes, steps, step_size)
+    alphas = alphas.to(dev)
+    grads, logits = _path(x, base, alphas, model, batch_size, target_class)
+    w = torch.zeros(steps, device=dev)
+    w[1:] = (logits[0, 1:] - logits[0, :-1]) / (alphas[1:] - alphas[:-1])
+    return K.ig_accum(grads, x, base, w1=w.reshape(1, steps).contiguous(), w2=substep.to(dev).reshape(1, steps).contiguous())[0]
+
+
+def IDGI(input, model, steps, batch_size, baseline, device, target_class):
+    """IDGI (reference saliencyMethods.py:139-181)."""
+    if steps % batch_size != 0:
+        print("steps must be evenly divisible by batch size: " + str(batch_size) + "!")
+        return 0, 0, 0, 0
+    dev, x, base = _prep(input, baseline, device)
+    grads, logits = _path(x, base, torch.linspace(0, 1, steps).to(dev), model, batch_size, target_class)
+    g = grads[0]
+    return K.idgi_accum(g, logits[0].contiguous(), K.sumsq(g))
+
+
+def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_pass=4, want_abs=False,
+             grads_buffer=None):
+    """Multi-image IG / Left-IG: x (B,C,H,W) on a HIP device, targets (B,) long.
+    `images_per_pass` images x `steps` interpolants go through the classifier at once; all
+    step gradients land in one [B][steps][C][H][W] buffer that a single accumulation launch
+    reduces (per-image Left-IG cutoffs are computed on the device, no host sync).
+    Returns (B,C,H,W) [and the (B,H,W) |sum_c| map the metrics consume]."""
+    if not x.is_cuda:
+        raise XaiHipError("ig_batch needs its input on a HIP device")
+    x = x.float().contiguous()
+    B = x.shape[0]
+    dev = x.device
+    base = baseline.to(dev, torch.float32).contiguous() if torch.is_tensor(baseline) else float(baseline)
+    alphas = torch.linspace(0, 1, steps).to(dev)
+    shape = (B, steps) + tuple(x.shape[1:])
+    if grads_buffer is None:
+        grads_buffer = torch.empty(shape, dtype=torch.float32, device=dev)
+    elif tuple(grads_buffer.shape) != shape:
+        raise ValueError(f"grads_buffer must have shape {shape}")
+    logits = torch.empty((B, steps), dtype=torch.float32, device=dev)
+    targets = targets.to(dev).long().reshape(B)
+    for lo in range(0, B, images_per_pass):
+        hi = min(lo + images_per_pass, B)
+        b = base[lo:hi] if torch.is_tensor(base) else base
+        imgs = K.ig_interp(x[lo:hi], b, alphas)                                  # (k, steps, C,H,W)
+        flat = imgs.view((-1,) + tuple(x.shape[1:])).requires_grad_(True)
+        out = _logits_of(model(flat))
+        scores = out.gather(1, targets[lo:hi].repeat_interleave(steps).unsqueeze(1)).squeeze(1)
+        (g,) = torch.autograd.grad(scores, flat, grad_outputs=torch.ones_like(scores))
+        grads_buffer[lo:hi] = g.view(imgs.shape)
+        logits[lo:hi] = scores.detach().view(hi - lo, steps)
+    n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)
+    return K.ig_accum(grads_buffer, x, base, n_use=n_use, want_abs=want_abs)

@@ -1,0 +1,187 @@
+"""Device-resident insertion/deletion loop and the five metric classes built on it.
+
+Where the reference edits a NumPy view pixel by pixel on the host and ships every batch over
+PCIe (MASTestFunctions.py:245-281 and the same loop in RISE/AIC/PosNegPert/Monotonicity),
+this keeps start, finish and the per-pixel flip step on the GPU: K8 ranks the saliency map
+once, K6 materialises each batch of step images straight into the classifier's input buffer,
+K9 reduces the logits to (p[target], entropy, argmax) and only 3 x (n_steps+1) floats come
+back.  The 225-point curve arithmetic stays NumPy float64 on the host (curves.py).
+
+Class names, constructor/single_run signatures, mode strings, return tuples and the
+assert / print-and-return-zeros conventions are the reference's.
+"""
+import numpy as np
+import torch
+from scipy.stats import spearmanr
+
+from . import curves
+from . import kernels as K
+from .ig import hip_device, _logits_of
+
+
+class _Probe:
+    """softmax statistics of one forward pass, kept on the device."""
+
+    def __init__(self, logits, target=None):
+        self.p, self.entropy, self.argmax = K.softmax_stats(logits.float().contiguous(), target)
+
+
+class _PerturbationMetric:
+    MODES = ()
+    ALWAYS_LEFTOVER = False
+
+    def __init__(self, model, HW, mode, step_size, substrate_fn):
+        assert mode in self.MODES
+        self.model = model
+        self.HW = HW
+        self.mode = mode
+        self.step_size = step_size
+        self.substrate_fn = substrate_fn
+
+    # ---- what differs between metrics -------------------------------------------------
+    def _inserting(self):
+        return self.mode in ("ins", "positive")
+
+    def _descending(self):
+        return self.mode != "lerf"
+
+    # ---- classifier access --------------------------------------------------------------
+    def _logits(self, images, clip_info):
+        with torch.no_grad():
+            if clip_info is None:
+                return _logits_of(self.model(images)).detach()
+            emb = clip_info["embeddings"]
+            return (self.model.encode_image(images) @ emb.squeeze().T).detach()
+
+    # ---- the shared device pipeline ------------------------------------------------------
+    def _run(self, img_tensor, saliency_map, device, patch_mask, max_batch_size, clip_info=None, want_density=False):
+        dev = hip_device(device)
+        n_steps, step_size, batches = curves.step_plan(self.HW, self.step_size, max_batch_size, patch_mask, self.ALWAYS_LEFTOVER)
+        if patch_mask is not None:
+            self.step_size = step_size                      # the reference overwrites it too (:92)
+        temp = 0.1 if clip_info is not None else None       # CLIP similarities are softmaxed at T = 0.1
+
+        def stats(images, target):
+            lg = self._logits(images, clip_info)
+            return _Probe(lg / temp if temp else lg, target)
+
+        img = img_tensor.to(dev, torch.float32).contiguous()
+        substrate = self.substrate_fn(img_tensor).to(dev, torch.float32).contiguous()
+        if clip_info is None:
+            orig = stats(img, None)
+        else:
+            orig = stats(clip_info["input"].to(dev), None)
+        target = orig.argmax                                 # int32 (1,) on the device, never synced
+        sub = stats(substrate, target)
+        start, finish = (substrate, img) if self._inserting() else (img, substrate)
+
+        # pixel order -> flip step per pixel
+        seg = total = None
+        if patch_mask is None:
+            sal = torch.as_tensor(np.ascontiguousarray(saliency_map, dtype=np.float32)).reshape(1, self.HW).to(dev)
+            order, rk = K.rank(sal)
+            flip = K.flip_steps(rk[0], self._descending(), step_size)
+            if want_density:
+                seg, total = K.segment_sums(sal[0], order[0], self._descending(), step_size, n_steps)
+        else:
+            flip_np, _ = curves.patch_flip_steps(saliency_map, patch_mask, self.HW, n_steps, self._descending())
+            flip = torch.from_numpy(flip_np).to(dev)
+            if want_density:
+                seg, total = curves.patch_density_sums(saliency_map, flip_np, self.HW, n_steps)
+
+        # every step image through the classifier, in the reference's batch sizes
+        p = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
+        ent = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
+        am = torch.empty(n_steps + 1, dtype=torch.int32, device=dev)
+        first = sub if self._inserting() else orig
+        p[0:1], ent[0:1], am[0:1] = first.p, first.entropy, first.argmax
+        buf = torch.empty((max(batches) if batches else 0,) + tuple(img.shape[1:]), dtype=torch.float32, device=dev)
+        done = 0
+        for b in batches:
+            if b == 0:                                      # MonotonicityTest's empty remainder batch: nothing to add
+                continue
+            images = K.perturb_batch(start[0], finish[0], flip, done, b, out=buf[:b])
+            st = stats(images, target)
+            p[1 + done:1 + done + b], ent[1 + done:1 + done + b], am[1 + done:1 + done + b] = st.p, st.entropy, st.argmax
+            done += b
+
+        # one device->host transfer for everything the host arithmetic needs
+        host = torch.cat([p, ent, am.float(), orig.p, sub.p, sub.argmax.float(), target.float()]).cpu().numpy()
+        n1 = n_steps + 1
+        out = dict(n_steps=n_steps, response=host[:n1].astype(np.float64), entropy=host[n1:2 * n1].astype(np.float64),
+                   argmax=host[2 * n1:3 * n1].astype(np.int64), original_pred=float(host[3 * n1]),
+                   baseline_pred=float(host[3 * n1 + 1]), baseline_class=int(host[3 * n1 + 2]), target=int(host[3 * n1 + 3]))
+        if want_density:
+            if torch.is_tensor(seg):
+                seg, total = seg.cpu().numpy(), total.cpu().numpy()[0]
+            out["density"] = curves.density_curve(seg, total, self._inserting())
+        return out
+
+
+class MASMetric(_PerturbationMetric):
+    """reference util/test_methods/MASTestFunctions.py:55-385"""
+    MODES = ('del', 'ins', 'lerf', 'morf')
+
+    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, special_version=False,
+                   return_embeddings=False, CLIP_test_info=None):
+        if special_version or return_embeddings:
+            raise NotImplementedError("special_version (cvxopt QP smoothing) and return_embeddings are outside the accelerated path")
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info, want_density=True)
+        norm = curves.monotone_normalise(r["response"], r["baseline_pred"], r["original_pred"], falling=(self.mode != 'ins'))
+        corrected = curves.mas_correct(norm, r["density"], self.mode)
+        return r["n_steps"] + 1, corrected, r["entropy"], r["density"], norm
+
+
+class RISEMetric(_PerturbationMetric):
+    """reference util/test_methods/RISETestFunctions.py:34-237"""
+    MODES = ('del', 'ins', 'morf', 'lerf')
+
+    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, return_embeddings=False):
+        if return_embeddings:
+            raise NotImplementedError("return_embeddings is outside the accelerated path")
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size)
+        norm = curves.monotone_normalise(r["response"], r["baseline_pred"], r["original_pred"], falling=(self.mode != 'ins'))
+        return r["n_steps"] + 1, r["entropy"], norm
+
+
+class AICMetric(_PerturbationMetric):
+    """reference util/test_methods/AICTestFunctions.py:34-225: the statistic is argmax == target."""
+    MODES = ('del', 'ins')
+
+    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, decision_flip=False,
+                   CLIP_test_info=None):
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info)
+        response = (r["argmax"] == r["target"]).astype(np.float64)
+        original_pred = 1
+        baseline_pred = int(r["baseline_class"] == r["target"])
+        response[0] = baseline_pred if self.mode == 'ins' else original_pred
+        if decision_flip:
+            hit = np.where(response == (0 if self.mode == 'del' else 1))[0][0]
+            return hit / len(response), response
+        with np.errstate(divide="ignore", invalid="ignore"):
+            norm = curves.monotone_normalise(response, baseline_pred, original_pred, falling=(self.mode == 'del'))
+        return r["n_steps"] + 1, norm
+
+
+class PositiveNegativePerturbation(_PerturbationMetric):
+    """reference util/test_methods/PosNegPertFunctions.py:14-175: returns the RAW response."""
+    MODES = ('lerf', 'morf')
+
+    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, CLIP_test_info=None):
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info)
+        return r["n_steps"] + 1, r["response"]
+
+
+class MonotonicityMetric(_PerturbationMetric):
+    """reference util/test_methods/MonotonicityTest.py:34-213"""
+    MODES = ('positive', 'negative')
+    ALWAYS_LEFTOVER = True
+
+    def _descending(self):
+        return True
+
+    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, CLIP_test_info=None):
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info)
+        n1 = r["n_steps"] + 1
+        ramp = np.linspace(1, 0, n1) if self.mode == "negative" else np.linspace(0, 1, n1)
+        return r["response"], spearmanr(ramp, r["response"]).correlation

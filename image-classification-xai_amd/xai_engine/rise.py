@@ -1,0 +1,69 @@
+"""RISE on the HIP kernels (reference util/attribution_methods/CLIP/generate_emap.py:65-101).
+
+Bit-parity mode: the host draws the reference's NumPy RNG stream (one rand(N,s,s) block, then
+two randint per mask) -- 64 B + 8 B per mask -- and the GPU does the rest: K4 builds each
+masked batch in place (no N x H x W float64 mask tensor, no N x 3 x H x W masked tensor on the
+host), K5 regenerates the masks while accumulating score-weighted sums in fp64.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import kernels as K
+from .ig import hip_device
+
+
+def draw_masks(input_size, N, s, p1, rng=np.random):
+    """grid (N,s,s) uint8, shifts (N,2) int32 [row, col], cell (2,) -- generate_emap.py:66-76."""
+    cell = np.ceil(np.array(input_size) / s)
+    grid = (rng.rand(N, s, s) < p1).astype(np.uint8)
+    shifts = np.empty((N, 2), dtype=np.int32)
+    for i in range(N):
+        shifts[i, 0] = rng.randint(0, cell[0])
+        shifts[i, 1] = rng.randint(0, cell[1])
+    return grid, shifts, cell.astype(np.int64)
+
+
+def generate_masks(input_size, N, s, p1, device=None):
+    """(N,1,H,W) masks.  Same RNG stream and values as the reference; returned as float32 on the
+    HIP device instead of a float64 host tensor (documented divergence)."""
+    dev = hip_device(device if device is not None else "cuda")
+    grid, shifts, cell = draw_masks(tuple(int(v) for v in input_size), N, s, p1)
+    image = torch.zeros((1, int(input_size[0]), int(input_size[1])), dtype=torch.float32, device=dev)
+    masks = K.rise_apply(torch.from_numpy(grid).to(dev), torch.from_numpy(shifts).to(dev), cell, image,
+                         want_masked=False, want_masks=True)
+    return masks.unsqueeze(1)
+
+
+def rise(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=None, batch_size=50,
+         masks=None, mask_range=None, return_partial=False):
+    """Saliency (H,W) float32 on the device = sum_i score_i * mask_i / N / p1.
+
+    Reference call shape: rise(model, image, txt_embedding, device, N, s, p1) with the CLIP cosine
+    score.  Extensions (keyword-only): `score_fn(batch) -> (B,)` for a plain classifier,
+    `masks=(grid, shifts, cell)` to reuse a draw, `mask_range=(lo, hi)` to process a shard of the
+    masks (multi-GPU), `return_partial` to get the un-rounded fp64 partial sum for an all-reduce.
+    """
+    dev = hip_device(device)
+    H, W = int(image.shape[-2]), int(image.shape[-1])
+    grid, shifts, cell = masks if masks is not None else draw_masks((H, W), N, s, p1)
+    lo, hi = mask_range if mask_range is not None else (0, N)
+    img = image.to(dev, torch.float32).reshape(-1, H, W).contiguous()
+    g_all = torch.from_numpy(np.ascontiguousarray(grid[lo:hi])).to(dev)
+    sh_all = torch.from_numpy(np.ascontiguousarray(shifts[lo:hi])).to(dev)
+    n = hi - lo
+    scores = torch.empty(n, dtype=torch.float32, device=dev)
+    buf = torch.empty((min(batch_size, max(n, 1)),) + tuple(img.shape), dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        for i in range(0, n, batch_size):
+            j = min(i + batch_size, n)
+            masked = K.rise_apply(g_all[i:j], sh_all[i:j], cell, img, out=buf[:j - i])
+            if score_fn is not None:
+                scores[i:j] = score_fn(masked).reshape(-1).float()
+            else:
+                feats = F.normalize(model.encode_image(masked), dim=-1)
+                scores[i:j] = (feats @ txt_embedding.T).reshape(-1).float()
+    acc = torch.zeros((H, W), dtype=torch.float64, device=dev)
+    if n > 0:
+        K.rise_accum(g_all, sh_all, scores, cell, H, W, 1.0 / N / p1, acc=acc)
+    return acc if return_partial else acc.float()

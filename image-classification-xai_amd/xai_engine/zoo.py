@@ -1,0 +1,156 @@
+"""Classifier architectures for synthetic benchmarks and tests (seeded random weights -- there
+is no network for checkpoints).  The hot path is model-agnostic: these exist only so that
+bench.py can run BASELINE.json's named configurations (ResNet-50, ViT-B/16).
+
+ResNet-50 is the standard v1.5 bottleneck network (stride on the 3x3 conv), the architecture
+behind torchvision.models.resnet50 that the reference harness family uses
+(evaluatePerturbation.py:627-640 instantiates its deeper siblings).  ViT-B/16 follows the
+layout of the reference's hooked model (util/attribution_methods/VIT_LRP/ViT_ig.py:57-253:
+patch 16, dim 768, depth 12, 12 heads, qkv bias, LayerNorm eps 1e-6, class token, learned
+position embedding) including its attention-map / attention-gradient hooks.
+"""
+import torch
+import torch.nn as nn
+
+
+# ------------------------------------------------------------------------------ ResNet-50
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=False)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNet(nn.Module):
+    def __init__(self, layers=(3, 4, 6, 3), num_classes=1000, width=64):
+        super().__init__()
+        self.inplanes = width
+        self.conv1 = nn.Conv2d(3, width, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.relu = nn.ReLU(inplace=False)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._make(width, layers[0], 1)
+        self.layer2 = self._make(width * 2, layers[1], 2)
+        self.layer3 = self._make(width * 4, layers[2], 2)
+        self.layer4 = self._make(width * 8, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(width * 8 * 4, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+        seq = [Bottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        seq += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def resnet50(seed=0, num_classes=1000, width=64):
+    torch.manual_seed(seed)
+    m = ResNet((3, 4, 6, 3), num_classes, width).eval()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m
+
+
+# ------------------------------------------------------------------------------ ViT-B/16 with hooks
+class Attention(nn.Module):
+    def __init__(self, dim, heads, qkv_bias=True):
+        super().__init__()
+        self.heads = heads
+        self.scale = (dim // heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.attention_map = None
+        self.attn_gradients = None
+
+    def save_attn_gradients(self, g):
+        self.attn_gradients = g
+
+    def get_attn_gradients(self):
+        return self.attn_gradients
+
+    def get_attention_map(self):
+        return self.attention_map
+
+    def forward(self, x, register_hook=False):
+        B, N, D = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.heads, D // self.heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        attn = ((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1)
+        self.attention_map = attn
+        if register_hook and attn.requires_grad:
+            attn.register_hook(self.save_attn_gradients)
+        return self.proj((attn @ v).transpose(1, 2).reshape(B, N, D))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, heads, mlp_ratio=4.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = nn.Sequential(nn.Linear(dim, int(dim * mlp_ratio)), nn.GELU(), nn.Linear(int(dim * mlp_ratio), dim))
+
+    def forward(self, x, register_hook=False):
+        x = x + self.attn(self.norm1(x), register_hook)
+        return x + self.mlp(self.norm2(x))
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img=224, patch=16, dim=768, depth=12, heads=12, num_classes=1000):
+        super().__init__()
+        self.patch_embed = nn.Conv2d(3, dim, patch, stride=patch)
+        n = (img // patch) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, dim))
+        self.blocks = nn.ModuleList([Block(dim, heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.head = nn.Linear(dim, num_classes)
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, x, register_hook=False):
+        B = x.shape[0]
+        x = self.patch_embed(x).flatten(2).transpose(1, 2)
+        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed
+        for blk in self.blocks:
+            x = blk(x, register_hook)
+        return self.head(self.norm(x)[:, 0])
+
+
+def vit_base_patch16_224(seed=0, **kw):
+    torch.manual_seed(seed)
+    m = VisionTransformer(**kw).eval()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m

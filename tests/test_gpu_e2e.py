@@ -1,0 +1,202 @@
+"""End-to-end parity on a real MI355X through the reference's own module paths and call
+signatures (image-classification-xai_amd/util/...), i.e. written the way a test of the
+reference would read.
+
+Two comparisons per feature:
+  (a) against the CPU oracle driving the SAME device-resident classifier -> isolates the HIP
+      path from MIOpen-vs-oneDNN convolution rounding; bar 1e-5 (BASELINE.json);
+  (b) against the golden vectors the reference produced on the CPU -> includes classifier
+      rounding differences between devices.  For gradients of a ReLU network this is not a
+      rounding-sized effect: a pre-activation within ~1e-7 of zero flips its gate between
+      oneDNN and MIOpen and changes that pixel's gradient by O(1), so the bar for (b) is
+      2e-3 on IG-type maps and 1e-4 on probability curves (documented in DESIGN.md).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_inf
+from helpers import tiny_from, logits_fn_of
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def attr():
+    from util.attribution_methods import saliencyMethods
+    return saliencyMethods
+
+
+# ------------------------------------------------------------------------------ IG family
+@pytest.mark.parametrize("name", ["ig_small.npz", "ig_224.npz"])
+def test_IG_signature_and_parity(attr, name):
+    from oracle import ig as oig
+    g = load_golden(name)
+    model = tiny_from(g, DEV)
+    x = torch.from_numpy(g["x"])
+    target = torch.tensor(int(g["target"]))
+    cases = [
+        ((50, 25, 1, 0), "ig"), ((50, 25, .9, 0), "lig"), ((50, 50, 1, torch.from_numpy(g["baseline_tensor"])), "ig_tensor_baseline"),
+        ((50, 10, .5, .25), "lig_a05_b025"),
+    ]
+    for (steps, bs, a_star, base), key in cases:
+        got = attr.IG(x.clone(), model, steps, bs, a_star, base, DEV, target)
+        assert got.shape == (3,) + x.shape[2:] and got.is_cuda
+        got = got.cpu().numpy()
+        base_np = base.numpy() if torch.is_tensor(base) else base
+        want = oig.ig(g["x"], model, steps, bs, a_star, base_np, int(target))           # (a) same device model
+        assert rel_inf(got, want) <= 1e-5, (key, rel_inf(got, want))
+        assert rel_inf(got, g[key]) <= 2e-3, (key, rel_inf(got, g[key]))                  # (b) reference on CPU
+    assert attr.IG(x, model, 50, 7, 1, 0, DEV, target) == (0, 0, 0, 0)                  # quirk kept
+
+
+def test_ig_batch_equals_per_image(attr):
+    from xai_engine.ig import ig_batch
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    gen = torch.Generator().manual_seed(5)
+    xs = torch.randn(5, 3, 32, 32, generator=gen)
+    with torch.no_grad():
+        targets = model(xs.to(DEV)).argmax(1)
+    for a_star in (1, .9):
+        out, out_abs = ig_batch(xs.to(DEV), model, targets, steps=50, alpha_star=a_star, images_per_pass=2, want_abs=True)
+        for i in range(5):
+            one = attr.IG(xs[i:i + 1], model, 50, 50, a_star, 0, DEV, targets[i])
+            assert rel_inf(out[i].cpu().numpy(), one.cpu().numpy()) <= 2e-6
+            assert rel_inf(out_abs[i].cpu().numpy(), np.abs(one.cpu().numpy().sum(0))) <= 2e-6
+
+
+def test_IDG_IDGI_and_helpers(attr):
+    from oracle import ig as oig
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    x = torch.from_numpy(g["x"])
+    t = torch.tensor(int(g["target"]))
+    slopes, step = attr.getSlopes(torch.zeros_like(x), x.clone(), model, 50, 25, DEV, t)
+    assert step == float(g["slope_step"])
+    assert rel_inf(slopes.cpu().numpy(), g["slopes"]) <= 1e-3
+    al, sub = attr.getAlphaParameters(torch.from_numpy(g["slopes"]), 50, float(g["slope_step"]))
+    np.testing.assert_array_equal(al.numpy(), g["idg_alphas"])
+    np.testing.assert_array_equal(sub.numpy(), g["idg_substep"])
+    idgi = attr.IDGI(x.clone(), model, 50, 25, 0, DEV, t).cpu().numpy()
+    assert rel_inf(idgi, oig.idgi(g["x"], model, 50, 25, 0, int(t))) <= 1e-4
+    assert rel_inf(idgi, g["idgi"]) <= 1e-3
+    idg = attr.IDG(x.clone(), model, 50, 25, 0, DEV, t).cpu().numpy()
+    assert rel_inf(idg, g["idg"]) <= 5e-3            # slope weights are differences of near-equal logits
+    xg = x.clone().to(DEV)
+    ig_ = attr.input_grad(xg, model, t)
+    assert rel_inf(ig_.cpu().numpy(), g["input_grad"]) <= 1e-5
+
+
+def test_smoothGrad_quirk(attr):
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    x = torch.from_numpy(g["x"]).to(DEV)
+    torch.manual_seed(0)
+    sg = attr.smoothGrad("IG", x, model, 10, 0, torch.tensor(int(g["target"])), DEV, samples=3)
+    assert sg.shape == (3, 32, 32)
+    np.testing.assert_array_equal(sg[0].cpu().numpy(), sg[1].cpu().numpy())       # only channel 0 survives (:196)
+    torch.manual_seed(0)
+    mean, total, noisy = attr.smoothGrad("IG", x, model, 10, 0, torch.tensor(int(g["target"])), DEV, samples=3, vis=True)
+    assert total.shape == (3, 3, 32, 32) and noisy.shape == (3, 3, 32, 32)
+    np.testing.assert_array_equal(mean.cpu().numpy(), sg.cpu().numpy())
+    from util.attribution_methods.saliencyMethods import IG
+    want0 = torch.stack([IG(noisy[i:i + 1], model, 10, 5, 1, 0, DEV, int(g["target"]))[0] for i in range(3)]).double().mean(0)
+    assert rel_inf(sg[0].cpu().numpy(), want0.cpu().numpy()) <= 2e-6
+
+
+# ------------------------------------------------------------------------------ ins/del metrics
+CASES = [
+    ("MAS_ins", "MASTestFunctions", "MASMetric", "ins", True, "mas"), ("MAS_del", "MASTestFunctions", "MASMetric", "del", False, "mas"),
+    ("MAS_lerf", "MASTestFunctions", "MASMetric", "lerf", False, "mas"), ("MAS_morf", "MASTestFunctions", "MASMetric", "morf", False, "mas"),
+    ("RISE_ins", "RISETestFunctions", "RISEMetric", "ins", True, "rise_metric"), ("RISE_del", "RISETestFunctions", "RISEMetric", "del", False, "rise_metric"),
+    ("RISE_lerf", "RISETestFunctions", "RISEMetric", "lerf", False, "rise_metric"),
+    ("AIC_ins", "AICTestFunctions", "AICMetric", "ins", True, "aic"), ("AIC_del", "AICTestFunctions", "AICMetric", "del", False, "aic"),
+    ("PNP_lerf", "PosNegPertFunctions", "PositiveNegativePerturbation", "lerf", False, "pnp"),
+    ("PNP_morf", "PosNegPertFunctions", "PositiveNegativePerturbation", "morf", False, "pnp"),
+    ("MONO_positive", "MonotonicityTest", "MonotonicityMetric", "positive", True, "mono"),
+    ("MONO_negative", "MonotonicityTest", "MonotonicityMetric", "negative", False, "mono"),
+]
+
+
+@pytest.mark.parametrize("fixture", ["perturb_small.npz", "perturb_patch.npz", "perturb_224.npz"])
+def test_single_run_return_tuples(fixture):
+    import importlib
+    from oracle import perturb as op
+    g = load_golden(fixture)
+    model = tiny_from(g, DEV)
+    fn = logits_fn_of(model)
+    x = torch.from_numpy(g["x"])
+    sal = g["saliency"]
+    HW = x.shape[-1] * x.shape[-2]
+    pm = torch.from_numpy(g["patch_mask"]) if "patch_mask" in g else None
+    klen, sig = int(g["blur_klen"]), int(g["blur_sig"])
+    MAS = importlib.import_module("util.test_methods.MASTestFunctions")
+    kern = MAS.gkern(klen, sig)
+    blur = lambda t: torch.nn.functional.conv2d(t, kern, padding=klen // 2)      # noqa: E731  the reference's own substrate_fn
+    okern = op.gkern(klen, sig)
+    oblur = lambda im: op.blur_dense(im, okern)                                   # noqa: E731
+    for tag, modname, clsname, mode, uses_blur, ofunc in CASES:
+        cls = getattr(importlib.import_module("util.test_methods." + modname), clsname)
+        metric = cls(model, HW, mode, int(g["step"]), substrate_fn=blur if uses_blur else torch.zeros_like)
+        res = metric.single_run(x.clone(), sal.copy(), DEV, patch_mask=pm, max_batch_size=int(g["max_bs"]))
+        want = getattr(op, ofunc)(fn, g["x"], sal, mode, int(g["step"]), oblur if uses_blur else np.zeros_like,
+                                  g["patch_mask"] if pm is not None else None, int(g["max_bs"]))
+        assert len(res) == len(want)
+        for i, (r, w) in enumerate(zip(res, want)):
+            gold = g[f"{tag}_ret{i}"]
+            if np.ndim(w) == 0 and not isinstance(w, float) and ofunc != "mono":
+                assert int(r) == int(w) == int(gold), (tag, i)
+                continue
+            assert rel_inf(r, w) <= 1e-5, (tag, i, rel_inf(r, w))                 # (a) oracle on the same device model
+            assert rel_inf(r, gold) <= 1e-4, (tag, i, rel_inf(r, gold))           # (b) reference on the CPU
+    if pm is None:
+        AIC = importlib.import_module("util.test_methods.AICTestFunctions")
+        score, resp = AIC.AICMetric(model, HW, "del", int(g["step"]), torch.zeros_like).single_run(
+            x.clone(), sal, DEV, max_batch_size=int(g["max_bs"]), decision_flip=True)
+        assert score == float(g["AIC_delflip_ret0"])
+        np.testing.assert_array_equal(resp, g["AIC_delflip_ret1"])
+
+
+def test_device_blur_substrate_and_mode_asserts():
+    from xai_engine.blur import GaussianBlur
+    from util.test_methods import MASTestFunctions as MAS
+    g = load_golden("perturb_224.npz")
+    model = tiny_from(g, DEV)
+    x = torch.from_numpy(g["x"])
+    blur = GaussianBlur(31, 31, DEV)
+    assert rel_inf(blur(x).cpu().numpy(), g["substrate_blur"]) <= 1e-5
+    m = MAS.MASMetric(model, 224 * 224, "ins", 224, substrate_fn=blur)
+    n, corrected, ent, dens, norm = m.single_run(x.clone(), g["saliency"], DEV, max_batch_size=50)
+    assert n == 225
+    for i, r in enumerate((n, corrected, ent, dens, norm)):
+        assert rel_inf(r, g[f"MAS_ins_ret{i}"]) <= 1e-4
+    with pytest.raises(AssertionError):
+        MAS.MASMetric(model, 224 * 224, "insert", 224, substrate_fn=blur)
+    assert abs(MAS.auc(np.linspace(0, 1, 225)) - 0.5) < 1e-15
+
+
+def test_model_utils_and_gradcam_call_shape():
+    from util import model_utils
+    from xai_engine.gradcam import LayerGradCam, gradcam_saliency
+    from oracle import gradcam as ogc
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    x = torch.from_numpy(g["x"])
+    pct, logit = model_utils.getPrediction(x, model, DEV, -1)
+    assert abs(float(pct) - float(g["pred_pct"])) <= 1e-5 and abs(float(logit) - float(g["pred_logit"])) <= 1e-4
+    assert int(model_utils.getClass(x, model, DEV)) == int(g["pred_class"])
+    assert int(model_utils.getClass(x, model, DEV, 2)) == int(g["pred_class_k2"])
+    gr = model_utils.getGradients(x.clone(), model, DEV, int(g["target"]))
+    assert rel_inf(gr.cpu().numpy(), g["input_grad"]) <= 1e-5
+    # Grad-CAM through captum's call shape on the conv layer of the tiny net
+    xd = x.to(DEV)
+    gc = LayerGradCam(model, model.conv).attribute(xd, torch.tensor(int(g["target"])), relu_attributions=True)
+    assert gc.shape == (1, 1, 32, 32)
+    act, grad = ogc.layer_act_and_grad(model, model.conv, xd, int(g["target"]))
+    want = ogc.cam_reduce(act, grad, relu=True)
+    assert np.abs(gc[0].cpu().numpy() - want).max() / np.abs(ogc.cam_reduce(act, grad, relu=False)).max() <= 1e-5
+    sal = gradcam_saliency(model, model.conv, xd, int(g["target"]), (64, 64))
+    assert rel_inf(sal.cpu().numpy(), ogc.gradcam_saliency(act, grad, 64, 64)) <= 1e-5

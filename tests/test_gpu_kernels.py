@@ -1,0 +1,350 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point (through ctypes, via
+xai_engine.kernels) against the CPU oracle / the reference-made golden vectors on identical
+inputs.  Integer/index/byte outputs are compared exactly; fp32 outputs with
+||a-b||inf/||b||inf <= 1e-5 (BASELINE.json's bar), usually far tighter as noted per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_inf
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def K():
+    from xai_engine import kernels
+    from xai_engine import load_library
+    load_library()
+    return kernels
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+# ------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("shape", [(3, 32, 32), (3, 224, 224), (3, 30, 45), (1, 7, 9)])
+def test_ig_interp_bit_exact(K, shape):
+    from oracle import ig as oig
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2,) + shape).astype(np.float32)
+    b = (rng.standard_normal((2,) + shape) * 0.3).astype(np.float32)
+    al = oig.linspace01(50)
+    want = np.stack([oig.interpolate(x[i], b[i], al) for i in range(2)])
+    got = K.ig_interp(dev(x), dev(b), dev(al)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)                     # mul then add, no FMA: bit-exact
+    want0 = np.stack([oig.interpolate(x[i], np.full(shape, 0.25, np.float32), al[10:17]) for i in range(2)])
+    got0 = K.ig_interp(dev(x), 0.25, dev(al)[10:17]).cpu().numpy()
+    np.testing.assert_array_equal(got0, want0)
+    # per-image schedules
+    al2 = np.stack([al[:5], al[20:25]])
+    got2 = K.ig_interp(dev(x), dev(b), dev(al2)).cpu().numpy()
+    for i in range(2):
+        np.testing.assert_array_equal(got2[i], oig.interpolate(x[i], b[i], al2[i]))
+
+
+# ------------------------------------------------------------------------------ K2
+def test_ig_accum_on_reference_gradients(K):
+    """The reference's own per-step gradients in, the reference's IG / Left-IG out."""
+    g = load_golden("ig_small.npz")
+    grads = dev(g["gradients"][None])                                     # (1,50,3,32,32)
+    x = dev(g["x"])
+    out, out_abs = K.ig_accum(grads, x, 0.0, want_abs=True)
+    assert rel_inf(out[0].cpu().numpy(), g["ig"]) <= 2e-6
+    assert rel_inf(out_abs[0].cpu().numpy(), np.abs(g["ig"].sum(0))) <= 2e-6
+    n_use = K.ig_cutoff(dev(g["logits"][None]), 0.9)
+    from oracle import ig as oig
+    assert int(n_use[0]) == oig.left_cutoff(g["logits"], 0.9)
+    lig = K.ig_accum(grads, x, 0.0, n_use=n_use)
+    assert rel_inf(lig[0].cpu().numpy(), g["lig"]) <= 2e-6
+    lig2 = K.ig_accum(grads, x, 0.0, n_use=int(n_use[0]))
+    np.testing.assert_array_equal(lig2.cpu().numpy(), lig.cpu().numpy())
+
+
+@pytest.mark.parametrize("shape,n_img,steps", [((3, 224, 224), 3, 50), ((3, 30, 45), 2, 7), ((1, 5, 5), 1, 1), ((3, 64, 64), 2, 19)])
+def test_ig_accum_vs_oracle(K, shape, n_img, steps):
+    from oracle import ig as oig
+    rng = np.random.default_rng(2)
+    grads = rng.standard_normal((n_img, steps) + shape).astype(np.float32)
+    x = rng.standard_normal((n_img,) + shape).astype(np.float32)
+    b = (rng.standard_normal((n_img,) + shape) * 0.2).astype(np.float32)
+    n_use = rng.integers(1, steps + 1, n_img).astype(np.int32)
+    out, out_abs = K.ig_accum(dev(grads), dev(x), dev(b), n_use=dev(n_use), want_abs=True)
+    for i in range(n_img):
+        want = oig.accumulate(grads[i], int(n_use[i]), x[i], b[i])
+        assert rel_inf(out[i].cpu().numpy(), want) <= 2e-6
+        assert rel_inf(out_abs[i].cpu().numpy(), np.abs(want.sum(0, dtype=np.float32))) <= 2e-6
+    # weighted (IDG) form: mean over ALL steps of g*w1*w2
+    w1 = rng.standard_normal((n_img, steps)).astype(np.float32)
+    w2 = rng.random((n_img, steps)).astype(np.float32)
+    got = K.ig_accum(dev(grads), dev(x), 0.5, w1=dev(w1), w2=dev(w2)).cpu().numpy()
+    for i in range(n_img):
+        wg = (grads[i] * w1[i].reshape(-1, 1, 1, 1)) * w2[i].reshape(-1, 1, 1, 1)
+        want = (wg.sum(0, dtype=np.float32) / np.float32(steps)) * (x[i] - np.float32(0.5))
+        assert rel_inf(got[i], want) <= 2e-6
+
+
+def test_ig_streaming_form_equals_buffered(K):
+    rng = np.random.default_rng(3)
+    grads = rng.standard_normal((1, 50, 3, 64, 64)).astype(np.float32)
+    x = rng.standard_normal((1, 3, 64, 64)).astype(np.float32)
+    acc = torch.zeros((1, 3, 64, 64), device=DEV)
+    g = dev(grads)
+    K.ig_accum_add(g[0, :25], acc)
+    K.ig_accum_add(g[0, 25:], acc)
+    a, a_abs = K.ig_finish(acc, 50, dev(x), 0.0, want_abs=True)
+    b, b_abs = K.ig_accum(g, dev(x), 0.0, want_abs=True)
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())       # same summation order
+    np.testing.assert_array_equal(a_abs.cpu().numpy(), b_abs.cpu().numpy())
+
+
+def test_ig_accum_linearity_full_size(K):
+    """Size-independent property at BASELINE's full size (32 images x 50 steps x 3x224x224,
+    963 MB): accum(a*G1 + G2) == a*accum(G1) + accum(G2) up to rounding, and a constant
+    gradient field integrates to exactly (x - b)."""
+    n_img, steps, shape = 32, 50, (3, 224, 224)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    g1 = torch.randn((n_img, steps) + shape, device=DEV, generator=gen)
+    x = torch.randn((n_img,) + shape, device=DEV, generator=gen)
+    ones = torch.ones_like(g1)
+    out = K.ig_accum(ones, x, 0.25)
+    np.testing.assert_array_equal(out.cpu().numpy(), (x - 0.25).cpu().numpy())
+    a1 = K.ig_accum(g1, x, 0.0)
+    ref = g1.double().mean(1) * x.double()
+    assert rel_inf(a1.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
+    g2 = g1 * 2.0                                                          # exact scaling in fp32
+    a2 = K.ig_accum(g2, x, 0.0)
+    np.testing.assert_array_equal(a2.cpu().numpy(), (a1 * 2.0).cpu().numpy())
+
+
+def test_idgi_kernels(K):
+    g = load_golden("ig_small.npz")
+    grads = dev(g["gradients"])
+    sq = K.sumsq(grads)
+    want_sq = (g["gradients"].astype(np.float64) ** 2).reshape(50, -1).sum(1)
+    assert rel_inf(sq.cpu().numpy(), want_sq) <= 2e-6
+    out = K.idgi_accum(grads, dev(g["logits"]), sq)
+    assert rel_inf(out.cpu().numpy(), g["idgi"]) <= 5e-5      # logit differences amplify the GPU/CPU 1-ulp gap
+
+
+# ------------------------------------------------------------------------------ K3
+@pytest.mark.parametrize("B,C,h,w", [(1, 2048, 7, 7), (3, 64, 14, 14), (2, 17, 5, 9), (1, 8, 32, 32)])
+def test_gradcam_and_upsample(K, B, C, h, w):
+    from oracle import gradcam as ogc
+    rng = np.random.default_rng(4)
+    act = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    grad = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    for relu in (True, False):
+        cam = K.gradcam(dev(act), dev(grad), relu=relu).cpu().numpy()
+        want = ogc.cam_reduce(act, grad, relu=relu)
+        # normalise by the un-ReLU'd magnitude: sums of ~C mixed-sign terms
+        scale = np.abs(ogc.cam_reduce(act, grad, relu=False)).max()
+        assert np.abs(cam - want).max() / scale <= TOL
+    cam = K.gradcam(dev(act), dev(grad), relu=True)
+    up = K.bilinear_up(cam, 224, 224).cpu().numpy()
+    assert rel_inf(up, ogc.bilinear_up(cam.cpu().numpy(), 224, 224)) <= 2e-6
+    sal = K.bilinear_up(cam, 224, 224, scale=3.0, take_abs=True).cpu().numpy()
+    assert rel_inf(sal, ogc.gradcam_saliency(act, grad, 224, 224)) <= TOL
+    # against the call the reference reaches (torch interpolate, antialias=True), on the GPU's own cam
+    want = torch.nn.functional.interpolate(cam[None].cpu(), size=(224, 224), mode="bilinear", align_corners=False,
+                                           antialias=True)[0].numpy()
+    assert rel_inf(up, want) <= 2e-6
+
+
+# ------------------------------------------------------------------------------ K4 / K5
+@pytest.mark.parametrize("H,W,s,N", [(224, 224, 8, 40), (30, 45, 7, 9), (32, 32, 4, 5)])
+def test_rise_masks_and_accumulate(K, H, W, s, N):
+    from oracle import rise as orise
+    rng = np.random.RandomState(5)
+    grid, shifts, cell = orise.draw_grid_and_shifts((H, W), N, s, 0.5, rng)
+    image = np.random.default_rng(6).standard_normal((3, H, W)).astype(np.float32)
+    g8, sh = dev(grid.astype(np.uint8)), dev(shifts)
+    masked, masks = K.rise_apply(g8, sh, cell, dev(image), want_masked=True, want_masks=True)
+    want_masks = orise.masks_from(grid, shifts, (H, W), cell)[:, 0]
+    assert np.abs(masks.cpu().numpy() - want_masks).max() <= 1e-6          # masks live in [0,1]
+    # masked = image * mask with the GPU's own mask is an exact fp32 product
+    np.testing.assert_array_equal(masked.cpu().numpy(), image[None] * masks.cpu().numpy()[:, None])
+    scores = np.random.default_rng(7).random(N).astype(np.float32)
+    acc = K.rise_accum(g8, sh, dev(scores), cell, H, W, 1.0 / N / 0.5)
+    want = (scores.reshape(-1, 1).astype(np.float64) * want_masks.reshape(N, -1)).sum(0).reshape(H, W) / N / 0.5
+    assert rel_inf(acc.cpu().numpy(), want) <= 2e-6
+    # accumulating in two calls == one call
+    acc2 = K.rise_accum(g8[: N // 2], sh[: N // 2], dev(scores[: N // 2]), cell, H, W, 1.0 / N / 0.5)
+    K.rise_accum(g8[N // 2:], sh[N // 2:], dev(scores[N // 2:]), cell, H, W, 1.0 / N / 0.5, acc=acc2)
+    assert rel_inf(acc2.cpu().numpy(), acc.cpu().numpy()) <= 1e-12
+
+
+def test_rise_full_rise_vs_oracle(K):
+    from oracle import rise as orise
+    from xai_engine.rise import rise
+    H = W = 64
+    N, s, p1 = 120, 8, 0.5
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(2),
+                              torch.nn.Flatten(), torch.nn.Linear(16, 5)).to(DEV).eval()
+    image = torch.randn(1, 3, H, W)
+    score = lambda b: torch.softmax(net(b), 1)[:, 2]          # noqa: E731
+    rng = np.random.RandomState(9)
+    grid, shifts, cell = orise.draw_grid_and_shifts((H, W), N, s, p1, rng)
+    got = rise(None, image, None, DEV, N=N, s=s, p1=p1, score_fn=score, masks=(grid.astype(np.uint8), shifts, cell))
+
+    def score_np(b):
+        with torch.no_grad():
+            return score(torch.from_numpy(b).to(DEV)).cpu().numpy()
+    want = orise.rise(score_np, image.numpy(), N, s, p1, grid, shifts, cell)
+    assert rel_inf(got.cpu().numpy(), want) <= TOL
+    # the host RNG stream is the reference's: same seed -> same draw
+    from xai_engine.rise import draw_masks
+    np.random.seed(11); a = draw_masks((H, W), 10, s, p1)
+    np.random.seed(11); b = orise.draw_grid_and_shifts((H, W), 10, s, p1)
+    np.testing.assert_array_equal(a[0], b[0].astype(np.uint8)); np.testing.assert_array_equal(a[1], b[1])
+
+
+# ------------------------------------------------------------------------------ K8 / K6 / K10
+@pytest.mark.parametrize("hw", [50176, 1024, 1000, 77, 1, 65536 + 3])
+def test_rank_exact_with_ties_and_specials(K, hw):
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal(hw).astype(np.float32)
+    b = np.maximum(a, 0)                                           # ReLU'd: half the map ties at 0
+    c = np.round(a * 4) / 4                                        # heavy ties, both signs, -0.0 present
+    c[::7] = -0.0
+    d = a.copy(); d[::5] = np.nan; d[1::11] = np.inf; d[2::13] = -np.inf
+    sal = np.stack([a, b, c.astype(np.float32), d])
+    order, rk = K.rank(dev(sal))
+    order, rk = order.cpu().numpy(), rk.cpu().numpy()
+    for i in range(sal.shape[0]):
+        want = np.argsort(sal[i], kind="stable")
+        np.testing.assert_array_equal(order[i], want)
+        inv = np.empty(hw, dtype=np.int64); inv[want] = np.arange(hw)
+        np.testing.assert_array_equal(rk[i], inv)
+
+
+def test_rank_matches_reference_order_on_tie_free_maps(K):
+    for name in ("perturb_small.npz", "perturb_224.npz"):
+        g = load_golden(name)
+        sal = g["saliency"].reshape(1, -1)
+        order, _ = K.rank(dev(sal))
+        np.testing.assert_array_equal(order.cpu().numpy()[0], g["salient_order_asc"][0])
+        np.testing.assert_array_equal(order.cpu().numpy()[0][::-1], g["salient_order_desc"][0])
+
+
+@pytest.mark.parametrize("fixture", ["perturb_small.npz", "perturb_224.npz"])
+def test_perturb_batches_bit_exact_vs_reference_images(K, fixture):
+    """K6 against the images the reference fed its model (all of them for 32x32; sha256 of
+    every one of the 224 step images for 224x224)."""
+    import hashlib
+    g = load_golden(fixture)
+    x = g["x"]
+    hw = x.shape[-1] * x.shape[-2]
+    step = int(g["step"])
+    sal = dev(g["saliency"].reshape(1, -1))
+    order, rk = K.rank(sal)
+    blurred, zeros = g["substrate_blur"], np.zeros_like(x)
+    for tag, desc, start, finish in (("MAS_ins", True, blurred, x), ("MAS_del", True, x, zeros), ("MAS_lerf", False, x, zeros)):
+        flip = K.flip_steps(rk[0], desc, step)
+        n_steps = (hw + step - 1) // step
+        imgs = []
+        at = 0
+        for b in g[f"{tag}_batch_sizes"]:
+            imgs.append(K.perturb_batch(dev(start[0]), dev(finish[0]), flip, at, int(b)).cpu().numpy())
+            at += int(b)
+        imgs = np.concatenate(imgs)
+        assert imgs.shape[0] == n_steps
+        sha = [hashlib.sha256(np.ascontiguousarray(im).tobytes()).hexdigest() for im in imgs]
+        assert sha == list(g[f"{tag}_img_sha"]), tag
+        if f"{tag}_images" in g:
+            np.testing.assert_array_equal(imgs, g[f"{tag}_images"])
+        np.testing.assert_array_equal(imgs[-1], finish[0])                 # last step == finish
+
+
+def test_perturb_odd_shape_and_patch_steps(K):
+    from oracle import perturb as op
+    rng = np.random.default_rng(10)
+    C, H, W, step = 2, 9, 11, 7                                            # hw = 99: scalar path, ragged last step
+    start = rng.standard_normal((C, H, W)).astype(np.float32)
+    finish = rng.standard_normal((C, H, W)).astype(np.float32)
+    sal = rng.standard_normal(H * W).astype(np.float32)
+    plan = op.Plan(H * W, step, 4, None)
+    groups, _ = op.flip_groups(sal, H * W, plan, None, descending=True)
+    want = np.stack(list(op.sequence(start[None], finish[None], groups)))
+    _, rk = K.rank(dev(sal[None]))
+    flip = K.flip_steps(rk[0], True, step)
+    got = K.perturb_batch(dev(start), dev(finish), flip, 0, plan.n_steps).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    got_tail = K.perturb_batch(dev(start), dev(finish), flip, 5, 3).cpu().numpy()
+    np.testing.assert_array_equal(got_tail, want[5:8])
+
+
+def test_segment_sums(K):
+    g = load_golden("perturb_224.npz")
+    sal = g["saliency"].reshape(-1)
+    order, _ = K.rank(dev(sal[None]))
+    for desc in (True, False):
+        seg, total = K.segment_sums(dev(sal), order[0], desc, 224, 224)
+        o = np.argsort(sal, kind="stable")
+        o = o[::-1] if desc else o
+        want = np.array([sal[o[i * 224:(i + 1) * 224]].sum(dtype=np.float64) for i in range(224)])
+        assert rel_inf(seg.cpu().numpy(), want) <= 2e-6
+        assert abs(float(total[0]) - sal.sum(dtype=np.float64)) / sal.sum(dtype=np.float64) <= 2e-6
+
+
+# ------------------------------------------------------------------------------ K7 / K9
+def test_blur_vs_reference_conv2d(K):
+    from oracle import perturb as op
+    g = load_golden("kern.npz")
+    for klen, sig, xk, wk in ((31, 31, "blur_x", "blur_31_31"), (11, 5, "blur_x", "blur_11_5"), (31, 31, "blur_small_x", "blur_small_31_31")):
+        v = dev(op.gkern1d(klen, sig).astype(np.float32))
+        got = K.blur_sep(dev(g[xk]), v).cpu().numpy()
+        assert rel_inf(got, g[wk]) <= TOL, (klen, sig, rel_inf(got, g[wk]))
+
+
+def test_softmax_stats(K):
+    from oracle import perturb as op
+    rng = np.random.default_rng(12)
+    z = (rng.standard_normal((37, 1000)) * 3).astype(np.float32)
+    p, ent, am = K.softmax_stats(dev(z), 5)
+    want = op.softmax_rows(z)
+    assert rel_inf(p.cpu().numpy(), want[:, 5]) <= 2e-6
+    assert rel_inf(ent.cpu().numpy(), op.entropy_bits(want)) <= 2e-6
+    np.testing.assert_array_equal(am.cpu().numpy(), z.argmax(1))
+    p2, _, _ = K.softmax_stats(dev(z), None)                                # each row's own argmax
+    assert rel_inf(p2.cpu().numpy(), want.max(1)) <= 2e-6
+    t = torch.tensor([7], dtype=torch.int32, device=DEV)
+    p3, _, _ = K.softmax_stats(dev(z), t)
+    assert rel_inf(p3.cpu().numpy(), want[:, 7]) <= 2e-6
+    # saturated row: p underflows to 0 -> entropy is NaN, like the reference's p*log2(p)
+    zz = np.zeros((1, 10), dtype=np.float32); zz[0, 0] = 200.0
+    _, e, _ = K.softmax_stats(dev(zz), 0)
+    assert np.isnan(e.cpu().numpy()[0]) and np.isnan(op.entropy_bits(op.softmax_rows(zz))[0])
+    # ties -> lowest index, 10-class rows (fewer classes than lanes)
+    z10 = np.zeros((3, 10), dtype=np.float32); z10[1, 3] = z10[1, 8] = 2.0
+    _, _, a = K.softmax_stats(dev(z10), 0)
+    np.testing.assert_array_equal(a.cpu().numpy(), [0, 3, 0])
+
+
+# ------------------------------------------------------------------------------ error behaviour
+def test_cpu_tensors_are_refused_not_silently_computed(K):
+    from xai_engine import XaiHipError
+    with pytest.raises(XaiHipError):
+        K.ig_interp(torch.zeros(1, 3, 4, 4), 0.0, torch.zeros(2))
+    from xai_engine.ig import IG
+    with pytest.raises(XaiHipError):
+        IG(torch.zeros(1, 3, 8, 8), torch.nn.Identity(), 10, 5, 1, 0, "cpu", 0)
+
+
+def test_abi_argument_errors(K):
+    from xai_engine import load_library
+    lib = load_library()
+    assert lib.xai_ig_interp_f32(None, None, 0.0, None, 0, 1, 1, 4, None, None) == -1
+    x = torch.zeros(8, device=DEV)
+    assert lib.xai_ig_interp_f32(x.data_ptr(), None, 0.0, x.data_ptr(), 0, 0, 1, 4, x.data_ptr(), None) == -2
+    assert lib.xai_gradcam_f32(x.data_ptr(), x.data_ptr(), 1, 1, 64, 64, 1, x.data_ptr(), None) == -3
+    assert lib.xai_blur_sep_f32(x.data_ptr(), x.data_ptr(), 4, 1, 1, 2, 2, x.data_ptr(), None) == -2
