@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: attributions/sec of 50-step Integrated Gradients on ResNet-50 at
+3x224x224 (BASELINE.json metric; config[1] "IG 50 steps, ResNet-50, 32-image batch").
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of 32 synthetic images per GPU:
+K1 interpolation -> classifier forward/backward (PyTorch-ROCm, fp32) for 32 x 50 interpolants
+-> K2 accumulation with the fused |sum_c| epilogue.  Inputs are resident in HBM before the
+timed region.  Images shard over ranks with no data-path collective (weak scaling): every rank
+works on its own 32 images; the timed region is bracketed by barrier + synchronize and the
+reported time is the MAX over ranks.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      the IG accumulation kernel (xai_ig_accum_f32): algorithmic bytes per launch
+                ((S+2)*4N per image) / mean launch duration measured with HIP events
+                inside the timed steps, against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (oracle/ig.py, a port of the reference's IG) on the host cores,
+                a bounded sample (one attribution), rank 0 at N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "image-classification-xai_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+STEPS_IG, C, H, W = 50, 3, 224, 224
+N_ELEM = C * H * W
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--images-per-pass", type=int, default=2, help="images x 50 interpolants per classifier pass")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels-last", type=int, default=0, help="1 = NHWC classifier weights (slower with MIOpen fp32 on gfx950)")
+    ap.add_argument("--miopen-find", type=int, default=0, help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
+    return ap.parse_args()
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline():
+    """Time the oracle's IG (reference algorithm, NumPy element-wise + torch CPU classifier) on
+    one synthetic image: 50 steps, batch 50 -- the same per-attribution work as the GPU leg."""
+    from oracle import ig as oig
+    from xai_engine.zoo import resnet50
+    torch.set_num_threads(host_cores())
+    model = resnet50(seed=0)
+    x = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(2)).numpy()
+    with torch.no_grad():
+        target = int(model(torch.from_numpy(x)).argmax(1)[0])
+    t0 = time.perf_counter()
+    oig.ig(x, model, STEPS_IG, 50, 1, 0, target)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "attributions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 attribution (IG {STEPS_IG} steps, batch 50, ResNet-50 fp32, 3x224x224) in {dt:.2f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import xai_engine
+    xai_engine.load_library()                      # no extension -> no benchmark
+    from xai_engine.ig import ig_batch
+    from xai_engine.zoo import resnet50
+
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    model = resnet50(seed=0).to(dev)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    B = args.images
+    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(2 + rank)).to(dev)
+    with torch.no_grad():
+        targets = model(x).argmax(1)
+    grads = torch.empty((B, STEPS_IG, C, H, W), dtype=torch.float32, device=dev)
+    events = []
+
+    def step(sink=None):
+        return ig_batch(x, model, targets, steps=STEPS_IG, alpha_star=1, baseline=0, images_per_pass=args.images_per_pass,
+                        want_abs=True, grads_buffer=grads, event_sink=sink)
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    log(f"model + inputs ready on {dev}; warmup x{args.warmup}")
+    for _ in range(args.warmup):
+        step()
+    fence()
+    log("warmup done; timing")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    log(f"timed {args.steps} steps in {dt:.3f} s")
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+    algo_bytes = B * (STEPS_IG + 2) * 4 * N_ELEM + B * H * W * 4      # read S grads + x, write out (+ |sum_c| map); b is a scalar
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "ig_accum_pmc.json")     # written from a separate rocprofv3 --pmc run
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "attributions/sec (IG 50-step ResNet-50 224^2)",
+            "value": world * B * args.steps / dt,
+            "unit": "attributions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "IG 50 steps, ResNet-50 (seeded random weights), 32-image batch of 3x224x224 per GPU, "
+                                   "alpha_star=1, baseline=0", "images_per_gpu": B, "ig_steps": STEPS_IG,
+                       "images_per_pass": args.images_per_pass, "parallelism": f"image-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "xai_ig_accum_f32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+                         "avg_launch_ms": kern_ms, "launches_timed": len(events)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,19 @@ static inline bool xai_aligned16(const void* p) { return (reinterpret_cast<uintp
 
 static inline int64_t xai_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Compute units of the current device (256 on MI355X); queried once per process and device.
+static inline int xai_cu_count() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 constexpr int kWave = 64;  // gfx950 wavefront
 
 // Wave-wide reductions over 64 lanes (butterfly through DPP/bpermute shuffles).

@@ -74,7 +74,7 @@ def _path(x, base, alphas, model, batch_size, target_class, want_grads=True):
         if want_grads:
             imgs.requires_grad_(True)
             g, s = getGradientsParallel(imgs, model, target_class)
-            grads[0, lo:hi] = g.reshape(grads[0, lo:hi].shape)
+            K.store_grads(g.contiguous(), grads[0, lo:hi])
         else:
             with torch.no_grad():
                 s = getPredictionParallel(imgs, model, target_class)
@@ -170,12 +170,14 @@ def IDGI(input, model, steps, batch_size, baseline, device, target_class):
 
 
 def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_pass=4, want_abs=False,
-             grads_buffer=None):
+             grads_buffer=None, event_sink=None):
     """Multi-image IG / Left-IG: x (B,C,H,W) on a HIP device, targets (B,) long.
     `images_per_pass` images x `steps` interpolants go through the classifier at once; all
     step gradients land in one [B][steps][C][H][W] buffer that a single accumulation launch
     reduces (per-image Left-IG cutoffs are computed on the device, no host sync).
-    Returns (B,C,H,W) [and the (B,H,W) |sum_c| map the metrics consume]."""
+    Returns (B,C,H,W) [and the (B,H,W) |sum_c| map the metrics consume].
+    `event_sink`: optional list that receives a (start, end) torch.cuda.Event pair bracketing
+    the accumulation kernel (used by bench.py for the roofline figure)."""
     if not x.is_cuda:
         raise XaiHipError("ig_batch needs its input on a HIP device")
     x = x.float().contiguous()
@@ -198,7 +200,15 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
         out = _logits_of(model(flat))
         scores = out.gather(1, targets[lo:hi].repeat_interleave(steps).unsqueeze(1)).squeeze(1)
         (g,) = torch.autograd.grad(scores, flat, grad_outputs=torch.ones_like(scores))
-        grads_buffer[lo:hi] = g.view(imgs.shape)
+        K.store_grads(g.contiguous(), grads_buffer[lo:hi])
         logits[lo:hi] = scores.detach().view(hi - lo, steps)
     n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)
-    return K.ig_accum(grads_buffer, x, base, n_use=n_use, want_abs=want_abs)
+    if event_sink is None:
+        return K.ig_accum(grads_buffer, x, base, n_use=n_use, want_abs=want_abs)
+    # bench.py: HIP events around the accumulation launch, on the stream it is launched on
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record(torch.cuda.current_stream(dev))
+    out = K.ig_accum(grads_buffer, x, base, n_use=n_use, want_abs=want_abs)
+    t1.record(torch.cuda.current_stream(dev))
+    event_sink.append((t0, t1))
+    return out

@@ -106,6 +106,15 @@ def ig_accum(grads, x, baseline, n_use=None, w1=None, w2=None, want_abs=False):
     return (out, out_abs) if want_abs else out
 
 
+def store_grads(src, dst):
+    """dst <- src (same element count, both contiguous) with streaming non-temporal stores."""
+    _need(src, F32, "src"); _need(dst, F32, "dst")
+    if src.numel() != dst.numel():
+        raise ValueError("src and dst differ in size")
+    _call("xai_ig_store_grads_f32", dst.device, _ptr(src), _ptr(dst), src.numel())
+    return dst
+
+
 def ig_accum_add(grads, acc):
     """acc (N elems) += sum over rows of grads (n_batch, N elems)."""
     _need(grads, F32, "grads"); _need(acc, F32, "acc")

@@ -72,6 +72,11 @@ int xai_ig_accum_f32(const float* grads, int n_img, int n_steps, const int32_t* 
                      const float* x, const float* baseline, float baseline_scalar, int C,
                      int64_t hw, float* out_chw, float* out_abs_hw, xai_stream_t stream);
 
+/* dst[e] = src[e] with non-temporal stores: files one classifier pass's step gradients into
+ * the [n_img][n_steps][C][hw] buffer without leaving dirty lines in the Infinity Cache
+ * replaces  `gradients[start:end] = ...` at saliencyMethods.py:46 */
+int xai_ig_store_grads_f32(const float* src, float* dst, int64_t n_elem, xai_stream_t stream);
+
 /* K2, streaming form: acc[e] += sum_{b<n_batch} grads[b][e]   (no [steps][N] buffer kept)
  * replaces  saliencyMethods.py:46 + :53 when alpha_star == 1 */
 int xai_ig_accum_add_f32(const float* grads, int n_batch, float* acc, int64_t n_elem,

@@ -25,7 +25,7 @@ def layer_act_and_grad(model, layer, x, target):
     keep = {}
     h = layer.register_forward_hook(lambda m, i, o: keep.__setitem__("a", o))
     try:
-        xt = torch.as_tensor(x)
+        xt = torch.as_tensor(x).detach().requires_grad_(True)     # frozen weights: the graph must start at the input
         out = model(xt)
         out = out if isinstance(out, torch.Tensor) else out.logits
         score = out[:, int(target)].sum()

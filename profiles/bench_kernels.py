@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark at BASELINE shapes (HIP events, median of N launches): achieved
+algorithmic GB/s of every C-ABI kernel against the 8 TB/s HBM peak.  Run on the GPU box:
+    python profiles/bench_kernels.py [--json out.json]
+Working sets are sized past the 256 MiB Infinity Cache where the shape allows it."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "image-classification-xai_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from xai_engine import kernels as K  # noqa: E402
+
+DEV = "cuda:0"
+PEAK = 8000.0
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--json"); args = ap.parse_args()
+    res = []
+
+    def rep(name, nbytes, ms, note=""):
+        gbs = nbytes / ms / 1e6
+        res.append(dict(kernel=name, bytes=nbytes, us=ms * 1e3, gbs=gbs, frac=gbs / PEAK, note=note))
+        print(f"{name:34s} {nbytes / 1e6:10.1f} MB {ms * 1e3:9.1f} us {gbs:8.1f} GB/s  frac={gbs / PEAK:.3f}  {note}")
+
+    C, H, W = 3, 224, 224
+    N = C * H * W
+    B, S = 32, 50
+    g = torch.randn(B, S, C, H, W, device=DEV)
+    x = torch.randn(B, C, H, W, device=DEV)
+    al = torch.linspace(0, 1, S).to(DEV)
+    # K2
+    ms = timeit(lambda: K.ig_accum(g, x, 0.0, want_abs=True))
+    rep("ig_accum  32img x 50 steps (+abs)", B * (S + 2) * 4 * N + B * H * W * 4, ms)
+    nu = torch.full((B,), 37, dtype=torch.int32, device=DEV)
+    ms = timeit(lambda: K.ig_accum(g, x, 0.0, n_use=nu))
+    rep("ig_accum  Left-IG n_use=37", B * (37 + 2) * 4 * N, ms)
+    ms = timeit(lambda: K.ig_accum(g[:1], x[:1], 0.0, want_abs=True))
+    rep("ig_accum  1 image (cache-resident)", (S + 2) * 4 * N + H * W * 4, ms, "30 MB: Infinity-Cache resident")
+    # K1
+    out = torch.empty(B, S, C, H, W, device=DEV)
+    ms = timeit(lambda: K.ig_interp(x, 0.0, al, out=out))
+    rep("ig_interp 32img x 50 steps", B * (S + 1) * 4 * N, ms)
+    ms = timeit(lambda: K.ig_interp(x[:2], 0.0, al, out=out[:2]))
+    rep("ig_interp 2img x 50 steps", 2 * (S + 1) * 4 * N, ms, "60 MB")
+    # streaming add
+    acc = torch.zeros(C, H, W, device=DEV)
+    ms = timeit(lambda: K.ig_accum_add(g[0], acc))
+    rep("ig_accum_add 50 rows", (S + 2) * 4 * N, ms, "30 MB")
+    # K6
+    start, finish = x[0].contiguous(), torch.zeros_like(x[0])
+    sal = torch.rand(1, H * W, device=DEV)
+    ms = timeit(lambda: K.rank(sal))
+    rep("rank 50176 keys", 8 * H * W * 8 * 2, ms, "8 passes x (key+idx) r+w")
+    order, rk = K.rank(sal)
+    flip = K.flip_steps(rk[0], True, 224)
+    buf = torch.empty(224, C, H, W, device=DEV)
+    ms = timeit(lambda: K.perturb_batch(start, finish, flip, 0, 50, out=buf[:50]))
+    rep("perturb_batch 50 steps", 50 * 4 * N + 2 * 4 * N + 4 * H * W, ms, "30 MB")
+    ms = timeit(lambda: K.perturb_batch(start, finish, flip, 0, 224, out=buf))
+    rep("perturb_batch 224 steps", 224 * 4 * N + 2 * 4 * N + 4 * H * W, ms, "135 MB")
+    # K7
+    k1d = torch.ones(31, device=DEV) / 31
+    xb = torch.randn(32, C, H, W, device=DEV)
+    ms = timeit(lambda: K.blur_sep(xb, k1d))
+    rep("blur_sep 31 taps, 32 images", 2 * 32 * 4 * N, ms)
+    ms = timeit(lambda: K.blur_sep(xb[:1], k1d))
+    rep("blur_sep 31 taps, 1 image", 2 * 4 * N, ms)
+    # K3
+    act = torch.randn(32, 2048, 7, 7, device=DEV); grad = torch.randn(32, 2048, 7, 7, device=DEV)
+    ms = timeit(lambda: K.gradcam(act, grad))
+    rep("gradcam 32 x 2048x7x7", 2 * act.numel() * 4 + 32 * 49 * 4, ms)
+    ms = timeit(lambda: K.gradcam(act[:1], grad[:1]))
+    rep("gradcam 1 x 2048x7x7", 2 * 2048 * 49 * 4 + 49 * 4, ms, "latency-bound")
+    cam = K.gradcam(act, grad)
+    ms = timeit(lambda: K.bilinear_up(cam, 224, 224, 3.0, True))
+    rep("bilinear_up 32 x 7x7->224x224", 32 * (49 + H * W) * 4, ms)
+    # K4 / K5
+    n = 1000
+    grid = (torch.rand(n, 8, 8, device=DEV) < 0.5).to(torch.uint8)
+    sh = torch.randint(0, 28, (n, 2), device=DEV, dtype=torch.int32)
+    mbuf = torch.empty(n, C, H, W, device=DEV)
+    ms = timeit(lambda: K.rise_apply(grid, sh, (28, 28), x[0].contiguous(), out=mbuf), iters=10)
+    rep("rise_apply 1000 masks", n * 4 * N + 4 * N, ms, "602 MB written")
+    ms = timeit(lambda: K.rise_apply(grid[:50], sh[:50], (28, 28), x[0].contiguous(), out=mbuf[:50]))
+    rep("rise_apply 50 masks", 50 * 4 * N + 4 * N, ms, "30 MB")
+    sc = torch.rand(n, device=DEV)
+    ms = timeit(lambda: K.rise_accum(grid, sh, sc, (28, 28), H, W, 1.0), iters=10)
+    rep("rise_accum 1000 masks (regen)", n * (64 + 8 + 4) + H * W * 8, ms, f"{n * H * W / ms / 1e6:.1f} G mask-pixels/s (compute-bound)")
+    # K9
+    lg = torch.randn(50, 1000, device=DEV)
+    ms = timeit(lambda: K.softmax_stats(lg, 3))
+    rep("softmax_stats 50x1000", 50 * 1000 * 4, ms, "latency-bound")
+    if args.json:
+        json.dump(res, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
