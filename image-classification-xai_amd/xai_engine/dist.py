@@ -1,0 +1,81 @@
+"""One process per GPU over torch.distributed (backend "nccl" = RCCL on ROCm, xGMI underneath;
+"gloo" for the CPU rehearsal tests).  The hot path shards embarrassingly:
+
+  images      -> sweep.sweep_images: round-robin image ownership, ONE all-reduce(SUM) of an
+                 11-element fp64 vector (88 B) at the end            [evaluatePerturbation.py:594-618]
+  RISE masks  -> rise_sharded: contiguous mask ranges, ONE all-reduce(SUM) of the (H,W) fp64
+                 partial map (401 KB at 224x224)                      [generate_emap.py:93-100]
+
+Both messages are latency-bound (<= 0.4 MB); with 7 direct xGMI links per GPU RCCL's
+default algorithm is already one hop per peer, so nothing is tuned beyond "one collective".
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """(rank, world, device).  Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* set by torchrun."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if use_gpu else "gloo")
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+def mask_range(n_masks, rank, world):
+    """Contiguous, balanced [lo, hi) of masks for `rank`."""
+    base, extra = divmod(n_masks, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def broadcast_masks(masks, device, src=0):
+    """Make every rank use rank `src`'s RNG draw (grid uint8 (N,s,s), shifts int32 (N,2), cell (2,))."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return masks
+    on = device if dist.get_backend() == "nccl" else torch.device("cpu")
+    grid, shifts, cell = masks
+    tg = torch.from_numpy(np.ascontiguousarray(grid)).to(on)
+    ts = torch.from_numpy(np.ascontiguousarray(shifts)).to(on)
+    tc = torch.from_numpy(np.asarray(cell, dtype=np.int64)).to(on)
+    for t in (tg, ts, tc):
+        dist.broadcast(t, src=src)
+    return tg.cpu().numpy(), ts.cpu().numpy(), tc.cpu().numpy()
+
+
+def all_reduce_sum(t):
+    """In-place SUM across ranks (no-op for a single process); gloo needs a CPU tensor."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def rise_sharded(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=None, batch_size=50, masks=None):
+    """RISE with the N masks split over the ranks: every rank scores its contiguous range and
+    accumulates an fp64 partial; one all-reduce merges them.  Returns the (H,W) fp32 map on
+    every rank.  All ranks use rank 0's mask draw."""
+    from .rise import draw_masks, rise
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    H, W = int(image.shape[-2]), int(image.shape[-1])
+    if masks is None:
+        masks = draw_masks((H, W), N, s, p1)
+    masks = broadcast_masks(masks, torch.device(device))
+    part = rise(model, image, txt_embedding, device, N=N, s=s, p1=p1, score_fn=score_fn, batch_size=batch_size, masks=masks,
+                mask_range=mask_range(N, rank, world), return_partial=True)
+    return all_reduce_sum(part).float()

@@ -26,6 +26,27 @@ class _Probe:
         self.p, self.entropy, self.argmax = K.softmax_stats(logits.float().contiguous(), target)
 
 
+def sequence_stats(stats, start, finish, flip, n_steps, batches, target, first):
+    """Run one insertion/deletion sequence on the device.  `stats(images, target) -> _Probe`;
+    start/finish (C,H,W); flip (H*W,) int32; `first` = the _Probe of curve point 0.
+    Returns device tensors p[target], entropy, argmax of length n_steps + 1."""
+    dev = start.device
+    p = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
+    ent = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
+    am = torch.empty(n_steps + 1, dtype=torch.int32, device=dev)
+    p[0:1], ent[0:1], am[0:1] = first.p, first.entropy, first.argmax
+    buf = torch.empty((max(batches) if batches else 0,) + tuple(start.shape), dtype=torch.float32, device=dev)
+    done = 0
+    for b in batches:
+        if b == 0:                                      # MonotonicityTest's empty remainder batch: nothing to add
+            continue
+        images = K.perturb_batch(start, finish, flip, done, b, out=buf[:b])
+        st = stats(images, target)
+        p[1 + done:1 + done + b], ent[1 + done:1 + done + b], am[1 + done:1 + done + b] = st.p, st.entropy, st.argmax
+        done += b
+    return p, ent, am
+
+
 class _PerturbationMetric:
     MODES = ()
     ALWAYS_LEFTOVER = False
@@ -90,20 +111,8 @@ class _PerturbationMetric:
                 seg, total = curves.patch_density_sums(saliency_map, flip_np, self.HW, n_steps)
 
         # every step image through the classifier, in the reference's batch sizes
-        p = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
-        ent = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
-        am = torch.empty(n_steps + 1, dtype=torch.int32, device=dev)
         first = sub if self._inserting() else orig
-        p[0:1], ent[0:1], am[0:1] = first.p, first.entropy, first.argmax
-        buf = torch.empty((max(batches) if batches else 0,) + tuple(img.shape[1:]), dtype=torch.float32, device=dev)
-        done = 0
-        for b in batches:
-            if b == 0:                                      # MonotonicityTest's empty remainder batch: nothing to add
-                continue
-            images = K.perturb_batch(start[0], finish[0], flip, done, b, out=buf[:b])
-            st = stats(images, target)
-            p[1 + done:1 + done + b], ent[1 + done:1 + done + b], am[1 + done:1 + done + b] = st.p, st.entropy, st.argmax
-            done += b
+        p, ent, am = sequence_stats(stats, start[0], finish[0], flip, n_steps, batches, target, first)
 
         # one device->host transfer for everything the host arithmetic needs
         host = torch.cat([p, ent, am.float(), orig.p, sub.p, sub.argmax.float(), target.float()]).cpu().numpy()

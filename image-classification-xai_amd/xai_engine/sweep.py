@@ -1,0 +1,206 @@
+"""Harness counterpart of XAI_Survey/evaluations/evaluatePerturbation.py for the accelerated
+methods: attribution dispatch (get_CNN_attr :82-181), the ten perturbation numbers of one image
+(run_perturbation :448-497), and the image sweep with its Counter sum / CSV (:499-620), image-
+sharded over ranks with one RCCL all-reduce at the end.
+
+`run_perturbation` drives the eight metric objects exactly like the reference.
+`PerturbationSweep` computes the same ten numbers from the THREE distinct image sequences the
+eight runs contain (insert-blur-descending, delete-zero-descending, delete-zero-ascending;
+compare MASTestFunctions.py:137-185, AICTestFunctions.py:94-123, PosNegPertFunctions.py:73-119,
+MonotonicityTest.py:93-120): 3 + 3*n_steps classifier passes instead of ~8*(n_steps+3).
+"""
+import csv
+import os
+import time
+from collections import Counter
+
+import numpy as np
+import torch
+from scipy.stats import spearmanr
+
+from . import curves
+from . import kernels as K
+from .blur import GaussianBlur
+from .gradcam import gradcam_saliency
+from .ig import IG, IDG, getGradientsParallel, hip_device, _logits_of
+from .perturb import (AICMetric, MASMetric, MonotonicityMetric, PositiveNegativePerturbation, _Probe, sequence_stats)
+from .smooth import smoothGrad
+
+KEYS = ("MAS_ins", "MAS_del", "RISE_ins", "RISE_del", "AIC_ins", "AIC_del", "LERF_res", "MORF_res", "MONO_pos", "MONO_neg")
+CNN_ATTR_FUNCS = ("grad", "inp_x_grad", "ig", "lig", "idg", "sg", "gc")
+
+
+def get_CNN_attr(input_tensor, trans_img, target_class, testing_dict):
+    """(H,W) float32 numpy saliency map = |sum over channels| of the attribution
+    (reference evaluatePerturbation.py:82-181, the methods on the accelerated path)."""
+    model = testing_dict["models"][0]
+    batch_size = testing_dict["batch_size"]
+    img_hw = testing_dict["img_hw"]
+    device = testing_dict["device"]
+    attr_function = testing_dict["attr_func"]
+    steps, baseline = 50, 0
+    dev = hip_device(device)
+    if attr_function == "grad":
+        x = input_tensor.to(dev).detach().requires_grad_(True)
+        saliency_map, _ = getGradientsParallel(x, model, target_class)
+    elif attr_function == "inp_x_grad":
+        x = input_tensor.to(dev).detach().requires_grad_(True)
+        grad, _ = getGradientsParallel(x, model, target_class)
+        saliency_map = x.detach().squeeze() * grad
+    elif attr_function == "ig":
+        saliency_map = IG(input_tensor, model, steps, batch_size, 1, baseline, device, target_class)
+    elif attr_function == "lig":
+        saliency_map = IG(input_tensor, model, steps, batch_size, .9, baseline, device, target_class)
+    elif attr_function == "idg":
+        saliency_map = IDG(input_tensor, model, steps, batch_size, baseline, device, target_class)
+    elif attr_function == "sg":
+        saliency_map = smoothGrad("IG", input_tensor, model, 50, baseline, target_class, device)
+    elif attr_function == "gc":
+        # |cam_up + cam_up + cam_up| fused into the up-sample kernel (scale 3, abs)
+        return gradcam_saliency(model, model.layer4, input_tensor.to(dev), target_class, (img_hw, img_hw))[0].cpu().numpy()
+    else:
+        print("Model-attribution mismatch, please use --help.")
+        raise SystemExit
+    return np.abs(np.sum(saliency_map.detach().cpu().numpy(), axis=0))
+
+
+def run_perturbation(input_tensor, attribution, testing_dict, CLIP_test_info=None, blur=None):
+    """Eight single_run calls, ten numbers -- call for call the reference's run_perturbation
+    (evaluatePerturbation.py:448-497); the blur substrate runs on the device."""
+    img_hw = testing_dict["img_hw"]
+    step_size = img_hw
+    model = testing_dict["models"][0]
+    batch_size = testing_dict["batch_size"]
+    device = testing_dict["device"]
+    HW = img_hw * img_hw
+    blur = blur if blur is not None else GaussianBlur(31, 31, device)
+    z = torch.zeros_like
+    kw = dict(max_batch_size=batch_size, CLIP_test_info=CLIP_test_info)
+    _, MAS_ins, _, _, RISE_ins = MASMetric(model, HW, 'ins', step_size, blur).single_run(input_tensor, attribution, device, **kw)
+    _, MAS_del, _, _, RISE_del = MASMetric(model, HW, 'del', step_size, z).single_run(input_tensor, attribution, device, **kw)
+    _, AIC_ins = AICMetric(model, HW, 'ins', step_size, blur).single_run(input_tensor, attribution, device, **kw)
+    _, AIC_del = AICMetric(model, HW, 'del', step_size, z).single_run(input_tensor, attribution, device, **kw)
+    _, LERF_res = PositiveNegativePerturbation(model, HW, 'lerf', step_size, z).single_run(input_tensor, attribution, device, **kw)
+    _, MORF_res = PositiveNegativePerturbation(model, HW, 'morf', step_size, z).single_run(input_tensor, attribution, device, **kw)
+    _, MONO_pos = MonotonicityMetric(model, HW, 'positive', step_size, blur).single_run(input_tensor, attribution, device, **kw)
+    _, MONO_neg = MonotonicityMetric(model, HW, 'negative', step_size, z).single_run(input_tensor, attribution, device, **kw)
+    auc = curves.auc
+    return Counter({"MAS_ins": auc(MAS_ins), "MAS_del": auc(MAS_del), "RISE_ins": auc(RISE_ins), "RISE_del": auc(RISE_del),
+                    "AIC_ins": auc(AIC_ins), "AIC_del": auc(AIC_del), "LERF_res": auc(LERF_res), "MORF_res": auc(MORF_res),
+                    "MONO_pos": MONO_pos, "MONO_neg": MONO_neg})
+
+
+class PerturbationSweep:
+    """The same ten numbers from three device-resident sequences (see module docstring)."""
+
+    def __init__(self, model, img_hw, device, step_size=None, batch_size=50, klen=31, ksig=31):
+        self.model = model
+        self.dev = hip_device(device)
+        self.img_hw = img_hw
+        self.HW = img_hw * img_hw
+        self.step_size = step_size or img_hw
+        self.batch_size = batch_size
+        self.blur = GaussianBlur(klen, ksig, self.dev)
+
+    def _stats(self, images, target):
+        with torch.no_grad():
+            return _Probe(_logits_of(self.model(images)).detach(), target)
+
+    def run(self, input_tensor, attribution, return_curves=False):
+        dev = self.dev
+        n_steps, step, batches = curves.step_plan(self.HW, self.step_size, self.batch_size)
+        img = input_tensor.to(dev, torch.float32).contiguous()
+        blurred = self.blur(img)
+        zeros = torch.zeros_like(img)
+        orig = self._stats(img, None)
+        target = orig.argmax
+        pb = self._stats(blurred, target)
+        pz = self._stats(zeros, target)
+        sal = torch.as_tensor(np.ascontiguousarray(attribution, dtype=np.float32)).reshape(1, self.HW).to(dev)
+        order, rk = K.rank(sal)
+        f_desc = K.flip_steps(rk[0], True, step)
+        f_asc = K.flip_steps(rk[0], False, step)
+        seg_d, total = K.segment_sums(sal[0], order[0], True, step, n_steps)
+        ins = sequence_stats(self._stats, blurred[0], img[0], f_desc, n_steps, batches, target, pb)
+        dele = sequence_stats(self._stats, img[0], zeros[0], f_desc, n_steps, batches, target, orig)
+        lerf = sequence_stats(self._stats, img[0], zeros[0], f_asc, n_steps, batches, target, orig)
+        n1 = n_steps + 1
+        host = torch.cat([ins[0], ins[2].float(), dele[0], dele[2].float(), lerf[0], seg_d, total,
+                          orig.p, pb.p, pz.p, pb.argmax.float(), pz.argmax.float(), target.float()]).cpu().numpy().astype(np.float64)
+        r_ins, a_ins, r_del, a_del, r_lerf = (host[i * n1:(i + 1) * n1] for i in range(5))
+        seg = host[5 * n1:5 * n1 + n_steps].astype(np.float32)
+        tot = np.float32(host[5 * n1 + n_steps])
+        o_p, b_p, z_p, b_cls, z_cls, tgt = host[5 * n1 + n_steps + 1:]
+
+        norm_ins = curves.monotone_normalise(r_ins, b_p, o_p, falling=False)
+        norm_del = curves.monotone_normalise(r_del, z_p, o_p, falling=True)
+        mas_ins = curves.mas_correct(norm_ins, curves.density_curve(seg, tot, True), 'ins')
+        mas_del = curves.mas_correct(norm_del, curves.density_curve(seg, tot, False), 'del')
+        aic_i = (a_ins == tgt).astype(np.float64)
+        aic_d = (a_del == tgt).astype(np.float64)
+        aic_i[0], aic_d[0] = float(b_cls == tgt), 1.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            aic_ins = curves.monotone_normalise(aic_i, float(b_cls == tgt), 1, falling=False)
+            aic_del = curves.monotone_normalise(aic_d, float(z_cls == tgt), 1, falling=True)
+        auc = curves.auc
+        out = Counter({"MAS_ins": auc(mas_ins), "MAS_del": auc(mas_del), "RISE_ins": auc(norm_ins), "RISE_del": auc(norm_del),
+                       "AIC_ins": auc(aic_ins), "AIC_del": auc(aic_del), "LERF_res": auc(r_lerf), "MORF_res": auc(r_del),
+                       "MONO_pos": spearmanr(np.linspace(0, 1, n1), r_ins).correlation,
+                       "MONO_neg": spearmanr(np.linspace(1, 0, n1), r_del).correlation})
+        if return_curves:
+            return out, dict(ins=r_ins, dele=r_del, lerf=r_lerf, mas_ins=mas_ins, mas_del=mas_del)
+        return out
+
+
+# ------------------------------------------------------------------------------ image sweep, sharded over ranks
+def shard_indices(n_items, rank, world):
+    """Round-robin ownership: item i belongs to rank i % world (deterministic, order-preserving)."""
+    return list(range(rank, n_items, world))
+
+
+def reduce_counters(local_sum, n_local, device=None, group=None):
+    """One all-reduce(SUM) of [10 metric sums, images used] in fp64 (88 bytes) -> global Counter, count."""
+    import torch.distributed as dist
+    vec = torch.tensor([float(local_sum.get(k, 0.0)) for k in KEYS] + [float(n_local)], dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "nccl":
+            vec = vec.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+        vec = vec.cpu()
+    return Counter({k: float(vec[i]) for i, k in enumerate(KEYS)}), int(round(float(vec[-1])))
+
+
+def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fused=True, rank=0, world=1, testing_dict=None):
+    """Attribution + ten perturbation numbers for every image this rank owns; returns the
+    globally reduced (Counter of sums, images used, seconds in attribution).
+    images: sequence of (1,C,H,W) CPU/device tensors (already selected -- the order-dependent
+    filters of evaluatePerturbation.py:520-576 must run as a deterministic pre-pass so that the
+    1-GPU and N-GPU runs see the same list).  attr_fn(x, target) -> (H,W) float32 numpy map."""
+    dev = hip_device(device)
+    sweep = PerturbationSweep(model, img_hw, dev, batch_size=batch_size) if fused else None
+    td = testing_dict or {"models": [model], "img_hw": img_hw, "batch_size": batch_size, "device": str(dev)}
+    blur = GaussianBlur(31, 31, dev)
+    total, used, attr_time = {k: 0.0 for k in KEYS}, 0, 0.0
+    for i in shard_indices(len(images), rank, world):
+        x = images[i]
+        with torch.no_grad():
+            target = _logits_of(model(x.to(dev))).argmax(1)[0]
+        t0 = time.time()
+        sal = attr_fn(x, target)
+        attr_time += time.time() - t0
+        c = sweep.run(x, sal) if fused else run_perturbation(x.cpu(), sal, td, blur=blur)
+        for k in KEYS:                                   # plain sums: see DESIGN.md on the reference's Counter `+=`
+            total[k] += float(c[k])
+        used += 1
+    return (*reduce_counters(total, used, dev), attr_time)
+
+
+def write_csv(path, counter_sum, images_used, attr_time, total_time):
+    """rows `key,mean` for the ten metrics + the two runtime rows (reference :606-618)."""
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with open(path, "w") as f:
+        w = csv.writer(f)
+        for k in KEYS:
+            w.writerow([k, str(counter_sum[k] / images_used)])
+        w.writerow(["Attr Avg Runtime", str(attr_time / images_used)])
+        w.writerow(["Total Runtime", str(total_time)])

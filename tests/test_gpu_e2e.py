@@ -200,3 +200,81 @@ def test_model_utils_and_gradcam_call_shape():
     assert np.abs(gc[0].cpu().numpy() - want).max() / np.abs(ogc.cam_reduce(act, grad, relu=False)).max() <= 1e-5
     sal = gradcam_saliency(model, model.conv, xd, int(g["target"]), (64, 64))
     assert rel_inf(sal.cpu().numpy(), ogc.gradcam_saliency(act, grad, 64, 64)) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ harness counterpart (f1)
+def test_run_perturbation_and_fused_sweep_match_reference_counters():
+    """The 10-key Counter of evaluatePerturbation.run_perturbation: eight single_runs (reference
+    call flow) and the 3-sequence fused sweep, against the reference's own numbers."""
+    from xai_engine.sweep import run_perturbation, PerturbationSweep, KEYS
+    g = load_golden("sweep_small.npz")
+    model = tiny_from(g, DEV)
+    td = {"models": [model], "img_hw": 32, "batch_size": 50, "device": DEV}
+    fused = PerturbationSweep(model, 32, DEV, batch_size=50)
+    assert list(KEYS) == list(g["keys"])
+    for i in range(3):
+        x = torch.from_numpy(g["x"][i:i + 1])
+        sal = g["saliency"][i]
+        a = run_perturbation(x, sal, td)
+        b = fused.run(x, sal)
+        ref = dict(zip(KEYS, g[f"counter_{i}"]))
+        for k in KEYS:
+            assert abs(a[k] - b[k]) <= 1e-6, (k, a[k], b[k])              # dedupe changes nothing
+            assert abs(a[k] - ref[k]) <= 1e-4, (k, a[k], ref[k])          # vs the reference on the CPU
+
+
+class _WithLayer4(torch.nn.Module):
+    def __init__(self, tiny):
+        super().__init__()
+        self.layer4 = torch.nn.Sequential(tiny.conv, tiny.act)
+        self.tail = torch.nn.Sequential(tiny.pool, torch.nn.Flatten(), tiny.fc)
+
+    def forward(self, x):
+        return self.tail(self.layer4(x))
+
+
+def test_get_CNN_attr_dispatch():
+    from xai_engine.sweep import get_CNN_attr
+    from oracle import ig as oig
+    from oracle import gradcam as ogc
+    g = load_golden("ig_small.npz")
+    model = _WithLayer4(tiny_from(g, DEV))
+    x = torch.from_numpy(g["x"])
+    t = torch.tensor(int(g["target"]))
+    td = {"models": [model, model], "img_hw": 32, "batch_size": 25, "device": DEV}
+    want = {
+        "ig": np.abs(g["ig"].sum(0)), "lig": np.abs(g["lig"].sum(0)), "idg": np.abs(g["idg"].sum(0)),
+        "grad": np.abs(g["input_grad"].sum(0)), "inp_x_grad": np.abs((g["x"][0] * g["input_grad"]).sum(0)),
+    }
+    tol = {"ig": 2e-3, "lig": 2e-3, "idg": 5e-3, "grad": 1e-5, "inp_x_grad": 1e-5}
+    for name, w in want.items():
+        got = get_CNN_attr(x.clone(), None, t, dict(td, attr_func=name))
+        assert got.shape == (32, 32) and got.dtype == np.float32
+        assert rel_inf(got, w) <= tol[name], (name, rel_inf(got, w))
+    got = get_CNN_attr(x.clone(), None, t, dict(td, attr_func="gc"))
+    act, grad = ogc.layer_act_and_grad(model, model.layer4, x.to(DEV), int(t))
+    assert rel_inf(got, ogc.gradcam_saliency(act, grad, 32, 32)[0]) <= 1e-5
+    torch.manual_seed(1)
+    sg = get_CNN_attr(x.clone().to(DEV), None, t, dict(td, attr_func="sg"))
+    assert sg.shape == (32, 32) and np.isfinite(sg).all()
+    with pytest.raises(SystemExit):
+        get_CNN_attr(x, None, t, dict(td, attr_func="nope"))
+
+
+def test_sweep_images_single_rank_and_csv(tmp_path):
+    from xai_engine.sweep import sweep_images, write_csv, KEYS, PerturbationSweep
+    from xai_engine.ig import IG
+    g = load_golden("sweep_small.npz")
+    model = tiny_from(g, DEV)
+    images = [torch.from_numpy(g["x"][i:i + 1]) for i in range(3)]
+    sal_of = {i: g["saliency"][i] for i in range(3)}
+    calls = iter(range(3))
+    total, used, attr_t = sweep_images(images, model, DEV, lambda x, t: sal_of[next(calls)], img_hw=32, batch_size=50)
+    assert used == 3
+    for j, k in enumerate(KEYS):
+        assert abs(total[k] - sum(g[f"counter_{i}"][j] for i in range(3))) <= 3e-4, k
+    path = tmp_path / "pert_test_results" / "T" / "ig_3_images.csv"
+    write_csv(str(path), total, used, attr_t, 1.0)
+    rows = [r.split(",") for r in open(path).read().strip().splitlines()]
+    assert [r[0] for r in rows] == list(KEYS) + ["Attr Avg Runtime", "Total Runtime"]
+    assert abs(float(rows[0][1]) - total["MAS_ins"] / 3) < 1e-12
