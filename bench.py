@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--images-per-pass", type=int, default=2, help="images x 50 interpolants per classifier pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", type=int, default=0, help="1 = NHWC classifier weights (slower with MIOpen fp32 on gfx950)")
+    ap.add_argument("--fold-bn", type=int, default=0, help="1 = fold eval-mode BatchNorm into the convolutions (opt-in, see xai_engine/prepare.py)")
     ap.add_argument("--miopen-find", type=int, default=0, help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
     return ap.parse_args()
 
@@ -105,6 +106,9 @@ def main():
 
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     model = resnet50(seed=0).to(dev)
+    if args.fold_bn:
+        from xai_engine.prepare import fold_batchnorm
+        model = fold_batchnorm(model)
     if args.channels_last:
         model = model.to(memory_format=torch.channels_last)
     B = args.images
@@ -165,7 +169,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "IG 50 steps, ResNet-50 (seeded random weights), 32-image batch of 3x224x224 per GPU, "
                                    "alpha_star=1, baseline=0", "images_per_gpu": B, "ig_steps": STEPS_IG,
-                       "images_per_pass": args.images_per_pass, "parallelism": f"image-sharded x{world}, no data-path collective"},
+                       "images_per_pass": args.images_per_pass, "classifier_prep": "conv+bn folded" if args.fold_bn else "none", "parallelism": f"image-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "xai_ig_accum_f32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": kern_ms, "launches_timed": len(events)},

@@ -1,26 +1,27 @@
-// K8: stable ascending argsort of a saliency map (one 1024-lane workgroup per map) for gfx950.
+// K8: stable ascending argsort of saliency maps for gfx950 -- multi-workgroup LSD radix sort.
 //
-// LSD radix sort, 4-bit digits, keys + indices ping-pong through an L2-resident scratch (16 B per
-// pixel).  Every lane owns a contiguous run of the input; per pass
-//   count   : it counts its digits into its private LDS column cnt[digit][lane] (bank = lane % 32,
-//             conflict-free), loads issued 8 at a time;
-//   scan    : the 16 x 1024 counters are exclusive-scanned digit-major -- 16 independent wave
-//             shuffle scans per lane, the 16 x 16 wave totals scanned by one wave: 2 barriers;
-//   scatter : the lane scatters its run in order, so equal keys keep their input order
-//             (NumPy kind='stable').
-// A pass whose digit is the same for every key (sign/exponent nibbles of a non-negative map, for
-// instance) is skipped.  Key order is NumPy's: -0.0 == +0.0, NaN sorts last.  A final sweep
-// writes `order` and its inverse `rank`.
-#include <mutex>
+// 8-bit digits, 4 passes over (key, index) pairs that ping-pong through an L2-resident scratch.
+// Work is tiled by 1024 keys (grid = tiles x maps, so one 224x224 map already spreads over 49 CUs
+// and a batch of maps over the whole chip); a sort is 1 memset + 9 launches:
+//   hist    : (pass 0 only) per-tile digit histogram in LDS (ds_add) -> hist[0][tile][digit];
+//             the histograms of passes 1..3 are accumulated by the previous pass's scatter with
+//             global atomics on the DESTINATION tile (counts do not depend on arrival order)
+//   scan    : one 256-lane workgroup per map: lane = digit, running sum over tiles, wave-shuffle
+//             exclusive scan over digits -> offs[tile][digit]; flags an identity pass (every key in
+//             one bin, e.g. the sign/exponent byte of a non-negative map)
+//   scatter : each wave owns 256 consecutive keys, 4 rounds of 64 (coalesced dword loads); the
+//             stable rank inside a round comes from 8 ballots (lanes with the same digit),
+//             across rounds from a per-wave LDS counter row, across waves from a 4-row prefix;
+//             position = offs[digit][tile] + rank.  Equal keys keep their input order
+//             (NumPy kind='stable').  The last pass writes `order` and its inverse `rank` directly.
+// Key order is NumPy's: -0.0 == +0.0, NaN sorts last.
 #include "xai_common.h"
 
 namespace {
 
-constexpr int RT = 1024;         // lanes per workgroup
-constexpr int RD = 16;           // digits per pass (4 bits)
-constexpr int RW = RT / 64;      // waves
-constexpr int kPasses = 8;
-constexpr size_t kLdsBytes = (RD * RT + RD * RW + RD * RW + 4) * sizeof(uint32_t);
+constexpr int kTile = 1024;      // keys per workgroup
+constexpr int kBlock = 256;      // lanes per workgroup (4 waves x 4 rounds x 64 keys)
+constexpr int kBins = 256;
 
 __device__ __forceinline__ uint32_t sort_key(float v) {
   if (v != v) return 0xFFFFFFFFu;                       // NaN last
@@ -29,151 +30,212 @@ __device__ __forceinline__ uint32_t sort_key(float v) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(RT) void rank_kernel(const float* __restrict__ sal_all, int64_t hw, int32_t* __restrict__ order_all,
-                                                  int32_t* __restrict__ rank_all, uint32_t* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  uint32_t* cnt = lds;                        // [RD][RT]
-  uint32_t* wtot = lds + RD * RT;             // [RD][RW] wave totals
-  uint32_t* wex = wtot + RD * RW;             // [RD][RW] exclusive prefix of wtot in (digit, wave) order
-  uint32_t* flag = wex + RD * RW;             // [0] = 1 when the pass is the identity
-  const int seg = blockIdx.x;
+struct SegPtrs {
+  uint32_t* key[2];
+  uint32_t* idx[2];
+  uint32_t* hist[4]; // [pass][n_tiles][kBins]
+  uint32_t* offs;    // [n_tiles][kBins]
+  uint32_t* flag;    // [4] identity flag per pass
+};
+
+// scratch layout: front (zeroed by ONE memset per sort): [n_seg][8] identity flags, [n_seg][4][tiles][256]
+// histograms; then per map: key0 key1 idx0 idx1 offs
+__host__ __device__ inline size_t front_words(int n_seg, int n_tiles) {
+  return static_cast<size_t>(n_seg) * (8u + 4u * kBins * static_cast<size_t>(n_tiles));
+}
+__host__ __device__ inline size_t seg_words(int64_t hw, int n_tiles) {
+  return static_cast<size_t>(4 * hw) + static_cast<size_t>(kBins) * n_tiles;
+}
+
+__device__ __forceinline__ SegPtrs seg_ptrs(uint32_t* ws, int seg, int n_seg, int64_t hw, int n_tiles) {
+  SegPtrs p;
+  p.flag = ws + static_cast<size_t>(seg) * 8u;
+  uint32_t* h = ws + static_cast<size_t>(n_seg) * 8u + static_cast<size_t>(seg) * 4u * kBins * n_tiles;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p.hist[i] = h + static_cast<size_t>(i) * kBins * n_tiles;
+  uint32_t* b = ws + front_words(n_seg, n_tiles) + static_cast<size_t>(seg) * seg_words(hw, n_tiles);
+  p.key[0] = b; p.key[1] = b + hw; p.idx[0] = b + 2 * hw; p.idx[1] = b + 3 * hw;
+  p.offs = b + 4 * hw;
+  return p;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ uint32_t load_key(const float* sal, const uint32_t* kin, int64_t i) {
+  return FIRST ? sort_key(sal[i]) : kin[i];
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void rank_hist_kernel(const float* __restrict__ sal_all, int64_t hw, int n_tiles, int pass,
+                                                           uint32_t* __restrict__ ws) {
+  __shared__ uint32_t h[kBins];
+  const int seg = blockIdx.y, tile = blockIdx.x;
+  const SegPtrs p = seg_ptrs(ws, seg, gridDim.y, hw, n_tiles);
   const float* sal = sal_all + seg * hw;
+  const uint32_t* kin = p.key[pass & 1];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(tile) * kTile;
+#pragma unroll
+  for (int j = 0; j < kTile / kBlock; ++j) {
+    const int64_t i = base + j * kBlock + threadIdx.x;
+    if (i < hw) atomicAdd(&h[(load_key<FIRST>(sal, kin, i) >> (8 * pass)) & 255u], 1u);
+  }
+  __syncthreads();
+  p.hist[pass][tile * kBins + threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBins) void rank_scan_kernel(int64_t hw, int n_tiles, int pass, uint32_t* __restrict__ ws) {
+  __shared__ uint32_t wsum[kBins / 64];
+  const SegPtrs p = seg_ptrs(ws, blockIdx.x, gridDim.x, hw, n_tiles);
+  const uint32_t* __restrict__ hist = p.hist[pass];
+  uint32_t* __restrict__ offs = p.offs;
+  const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
+  uint32_t total = 0;                                     // coalesced: lane = digit, row = tile
+  int t = 0;
+  for (; t + 8 <= n_tiles; t += 8) {
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = hist[(t + u) * kBins + d];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) total += c[u];
+  }
+  for (; t < n_tiles; ++t) total += hist[t * kBins + d];
+  uint32_t incl = total;                                  // exclusive scan of the 256 digit totals
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  const bool one_bin = __any(total == static_cast<uint32_t>(hw));
+  __syncthreads();
+  uint32_t run = incl - total;
+  for (int w = 0; w < wave; ++w) run += wsum[w];
+  for (t = 0; t + 8 <= n_tiles; t += 8) {                 // within a digit: tiles in order
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = hist[(t + u) * kBins + d];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { offs[(t + u) * kBins + d] = run; run += c[u]; }
+  }
+  for (; t < n_tiles; ++t) { offs[t * kBins + d] = run; run += hist[t * kBins + d]; }
+  if (one_bin && lane == 0) p.flag[pass] = 1u;            // the wave that holds the full bin (flags were zeroed by the launcher)
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(kBlock) void rank_scatter_kernel(const float* __restrict__ sal_all, int64_t hw, int n_tiles, int pass,
+                                                              uint32_t* __restrict__ ws, int32_t* __restrict__ order_all,
+                                                              int32_t* __restrict__ rank_all) {
+  __shared__ uint32_t cw[kBlock / 64][kBins];             // per-wave running count of each digit
+  __shared__ uint32_t gbase[kBins];                       // offs[digit][tile]
+  const int seg = blockIdx.y, tile = blockIdx.x;
+  const SegPtrs p = seg_ptrs(ws, seg, gridDim.y, hw, n_tiles);
+  const float* sal = sal_all + seg * hw;
+  const uint32_t* kin = p.key[pass & 1];
+  const uint32_t* iin = p.idx[pass & 1];
+  uint32_t* kout = p.key[(pass & 1) ^ 1];
+  uint32_t* iout = p.idx[(pass & 1) ^ 1];
   int32_t* order = order_all + seg * hw;
   int32_t* rank = rank_all + seg * hw;
-  uint32_t* kbuf[2] = {ws + static_cast<int64_t>(seg) * 4 * hw, ws + static_cast<int64_t>(seg) * 4 * hw + hw};
-  uint32_t* ibuf[2] = {kbuf[1] + hw, kbuf[1] + 2 * hw};
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t ipt = (hw + RT - 1) / RT;
-  const int64_t lo = min(static_cast<int64_t>(t) * ipt, hw);
-  const int64_t hi = min(lo + ipt, hw);
-  const uint32_t n = static_cast<uint32_t>(hw);
+  const bool identity = p.flag[pass] != 0;                // uniform for the whole map
+  const int64_t base = static_cast<int64_t>(tile) * kTile + wave * 256;
 
-  int cur = -1;                               // -1: keys still come from `sal`, indices are the positions
-  for (int pass = 0; pass < kPasses; ++pass) {
-    const int shift = pass * 4;
-    const uint32_t* kin = cur < 0 ? nullptr : kbuf[cur];
-    const uint32_t* iin = cur < 0 ? nullptr : ibuf[cur];
-    const int nxt = cur < 0 ? 0 : cur ^ 1;
-    // ---- count
+  uint32_t key[4], idx[4], dig[4], loc[4];
+  bool live[4];
 #pragma unroll
-    for (int d = 0; d < RD; ++d) cnt[d * RT + t] = 0;
-    {
-      int64_t i = lo;
-      for (; i + 8 <= hi; i += 8) {
-        uint32_t k[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) k[u] = kin ? kin[i + u] : sort_key(sal[i + u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) cnt[((k[u] >> shift) & 15u) * RT + t] += 1;
-      }
-      for (; i < hi; ++i) {
-        const uint32_t k = kin ? kin[i] : sort_key(sal[i]);
-        cnt[((k >> shift) & 15u) * RT + t] += 1;
-      }
-    }
-    // ---- scan (digit-major): wave-level inclusive scans of all 16 digits, then the 256 wave totals
-    uint32_t c[RD], incl[RD];
-#pragma unroll
-    for (int d = 0; d < RD; ++d) {
-      c[d] = cnt[d * RT + t];
-      uint32_t v = c[d];
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(v, off, kWave);
-        if (lane >= off) v += up;
-      }
-      incl[d] = v;
-      if (lane == 63) wtot[d * RW + wave] = v;
-    }
-    __syncthreads();
-    if (wave == 0) {                           // 256 totals, 4 per lane, in (digit, wave) order
-      uint32_t a[4], s = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { a[j] = wtot[lane * 4 + j]; s += a[j]; }
-      uint32_t v = s;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(v, off, kWave);
-        if (lane >= off) v += up;
-      }
-      uint32_t run = v - s;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { wex[lane * 4 + j] = run; run += a[j]; }
-      // a digit (= 4 consecutive lanes' worth of totals) holding all n keys makes the pass the identity
-      const uint32_t dsum = s + __shfl_xor(s, 1, kWave) + __shfl_xor(s + __shfl_xor(s, 1, kWave), 2, kWave);
-      const bool all_in_one = __any(dsum == n);
-      if (lane == 0) flag[0] = all_in_one ? 1u : 0u;
-    }
-    __syncthreads();
-    if (flag[0]) continue;                     // uniform: every lane reads the same word after the barrier
-#pragma unroll
-    for (int d = 0; d < RD; ++d) cnt[d * RT + t] = wex[d * RW + wave] + incl[d] - c[d];
-    // ---- stable scatter of this lane's run
-    uint32_t* kout = kbuf[nxt];
-    uint32_t* iout = ibuf[nxt];
-    {
-      int64_t i = lo;
-      for (; i + 4 <= hi; i += 4) {
-        uint32_t k[4], x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          k[u] = kin ? kin[i + u] : sort_key(sal[i + u]);
-          x[u] = iin ? iin[i + u] : static_cast<uint32_t>(i + u);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t slot = ((k[u] >> shift) & 15u) * RT + t;
-          const uint32_t pos = cnt[slot];
-          cnt[slot] = pos + 1;
-          kout[pos] = k[u];
-          iout[pos] = x[u];
-        }
-      }
-      for (; i < hi; ++i) {
-        const uint32_t k = kin ? kin[i] : sort_key(sal[i]);
-        const uint32_t x = iin ? iin[i] : static_cast<uint32_t>(i);
-        const uint32_t slot = ((k >> shift) & 15u) * RT + t;
-        const uint32_t pos = cnt[slot];
-        cnt[slot] = pos + 1;
-        kout[pos] = k;
-        iout[pos] = x;
-      }
-    }
-    cur = nxt;
-    __syncthreads();   // workgroup-scope release/acquire of the scratch (same CU, same L1)
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = base + j * 64 + lane;
+    live[j] = i < hw;
+    key[j] = live[j] ? load_key<FIRST>(sal, kin, i) : 0u;
+    idx[j] = live[j] ? (FIRST ? static_cast<uint32_t>(i) : iin[i]) : 0u;
   }
-  // ---- emit order and its inverse (coalesced sweep)
-  const uint32_t* ifin = cur < 0 ? nullptr : ibuf[cur];
-  for (int64_t i = t; i < hw; i += RT) {
-    const uint32_t x = ifin ? ifin[i] : static_cast<uint32_t>(i);
-    order[i] = static_cast<int32_t>(x);
-    rank[x] = static_cast<int32_t>(i);
+  if (identity) {                                         // every key shares this digit: order unchanged
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = base + j * 64 + lane;
+      if (!live[j]) continue;
+      if (LAST) { order[i] = static_cast<int32_t>(idx[j]); rank[idx[j]] = static_cast<int32_t>(i); }
+      else {
+        kout[i] = key[j]; iout[i] = idx[j];
+        atomicAdd(p.hist[pass + 1] + (i >> 10) * kBins + ((key[j] >> (8 * (pass + 1))) & 255u), 1u);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) cw[w][t] = 0;
+  gbase[t] = p.offs[tile * kBins + t];
+  __syncthreads();
+  volatile uint32_t* myrow = cw[wave];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dig[j] = (key[j] >> (8 * pass)) & 255u;
+    // lanes of this round holding the same digit (idle lanes match nobody)
+    unsigned long long m = __ballot(live[j]);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long set = __ballot(live[j] && ((dig[j] >> b) & 1u));
+      m &= ((dig[j] >> b) & 1u) ? set : ~set;
+    }
+    const unsigned long long below = m & ((1ull << lane) - 1ull);
+    const uint32_t before = live[j] ? myrow[dig[j]] : 0u;
+    loc[j] = before + static_cast<uint32_t>(__popcll(below));
+    const bool leader = live[j] && (m >> lane) == 1ull;   // highest lane of its group
+    if (leader) myrow[dig[j]] = loc[j] + 1u;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // digit-wise exclusive prefix over the 4 waves (lane = digit)
+  {
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { const uint32_t c = cw[w][t]; cw[w][t] = run; run += c; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!live[j]) continue;
+    const uint32_t pos = gbase[dig[j]] + cw[wave][dig[j]] + loc[j];
+    if (LAST) { order[pos] = static_cast<int32_t>(idx[j]); rank[idx[j]] = static_cast<int32_t>(pos); }
+    else {
+      kout[pos] = key[j]; iout[pos] = idx[j];
+      // next pass's histogram, filed under the tile this key lands in
+      atomicAdd(p.hist[pass + 1] + (pos >> 10) * kBins + ((key[j] >> (8 * (pass + 1))) & 255u), 1u);
+    }
   }
 }
 
-std::once_flag g_attr_once;
-int g_attr_status = 0;
+inline int tiles_of(int64_t hw) { return static_cast<int>((hw + kTile - 1) / kTile); }
 
 }  // namespace
 
 XAI_EXPORT size_t xai_rank_workspace_bytes(int n_seg, int64_t hw) {
   if (n_seg <= 0 || hw <= 0) return 0;
-  return static_cast<size_t>(n_seg) * static_cast<size_t>(hw) * 4u * sizeof(uint32_t);
+  const int nt = tiles_of(hw);
+  return (front_words(n_seg, nt) + static_cast<size_t>(n_seg) * seg_words(hw, nt)) * sizeof(uint32_t);
 }
 
 XAI_EXPORT int xai_rank_f32(const float* sal, int n_seg, int64_t hw, int32_t* order, int32_t* rank, void* ws, size_t ws_bytes,
                             xai_stream_t stream) {
   XAI_REQUIRE_PTR(sal); XAI_REQUIRE_PTR(order); XAI_REQUIRE_PTR(rank); XAI_REQUIRE_PTR(ws);
   XAI_REQUIRE(n_seg > 0 && hw > 0, XAI_E_SHAPE);
-  XAI_REQUIRE(hw < (int64_t(1) << 31), XAI_E_UNSUPPORTED);
+  XAI_REQUIRE(hw < (int64_t(1) << 31) && n_seg <= 65535, XAI_E_UNSUPPORTED);
   XAI_REQUIRE(ws_bytes >= xai_rank_workspace_bytes(n_seg, hw), XAI_E_SHAPE);
-  std::call_once(g_attr_once, [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(kLdsBytes));
-    g_attr_status = (e == hipSuccess) ? 0 : static_cast<int>(e);
-  });
-  if (g_attr_status) return g_attr_status;
-  hipLaunchKernelGGL(rank_kernel, dim3(n_seg), dim3(RT), kLdsBytes, static_cast<hipStream_t>(stream), sal, hw, order, rank,
-                     static_cast<uint32_t*>(ws));
+  XAI_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 3u) == 0, XAI_E_SHAPE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint32_t* w = static_cast<uint32_t*>(ws);
+  const int n_tiles = tiles_of(hw);
+  // zero the identity flags and the four histograms of every map (stream-ordered, capturable)
+  hipError_t e = hipMemsetAsync(w, 0, front_words(n_seg, n_tiles) * sizeof(uint32_t), st);
+  if (e != hipSuccess) return static_cast<int>(e);
+  const dim3 grid(n_tiles, n_seg), blk(kBlock);
+  hipLaunchKernelGGL(rank_hist_kernel<true>, grid, blk, 0, st, sal, hw, n_tiles, 0, w);
+  for (int pass = 0; pass < 4; ++pass) {
+    hipLaunchKernelGGL(rank_scan_kernel, dim3(n_seg), dim3(kBins), 0, st, hw, n_tiles, pass, w);
+    if (pass == 0)      hipLaunchKernelGGL((rank_scatter_kernel<true, false>), grid, blk, 0, st, sal, hw, n_tiles, pass, w, order, rank);
+    else if (pass == 3) hipLaunchKernelGGL((rank_scatter_kernel<false, true>), grid, blk, 0, st, sal, hw, n_tiles, pass, w, order, rank);
+    else                hipLaunchKernelGGL((rank_scatter_kernel<false, false>), grid, blk, 0, st, sal, hw, n_tiles, pass, w, order, rank);
+  }
   return xai_launch_status();
 }

@@ -108,23 +108,46 @@ class Attention(nn.Module):
         return self.proj((attn @ v).transpose(1, 2).reshape(B, N, D))
 
 
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
 class Block(nn.Module):
     def __init__(self, dim, heads, mlp_ratio=4.0):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
         self.attn = Attention(dim, heads)
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
-        self.mlp = nn.Sequential(nn.Linear(dim, int(dim * mlp_ratio)), nn.GELU(), nn.Linear(int(dim * mlp_ratio), dim))
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, register_hook=False):
         x = x + self.attn(self.norm1(x), register_hook)
         return x + self.mlp(self.norm2(x))
 
 
+class PatchEmbed(nn.Module):
+    def __init__(self, patch, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, patch, stride=patch)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
 class VisionTransformer(nn.Module):
+    """Parameter names follow the reference's ViT_ig.py / timm (patch_embed.proj, blocks.N.attn.qkv,
+    blocks.N.mlp.fc1 ...), so state dicts interchange."""
+
     def __init__(self, img=224, patch=16, dim=768, depth=12, heads=12, num_classes=1000):
         super().__init__()
-        self.patch_embed = nn.Conv2d(3, dim, patch, stride=patch)
+        self.patch_embed = PatchEmbed(patch, dim)
         n = (img // patch) ** 2
         self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, dim))
@@ -141,7 +164,7 @@ class VisionTransformer(nn.Module):
 
     def forward(self, x, register_hook=False):
         B = x.shape[0]
-        x = self.patch_embed(x).flatten(2).transpose(1, 2)
+        x = self.patch_embed(x)
         x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed
         for blk in self.blocks:
             x = blk(x, register_hook)

@@ -18,6 +18,8 @@ What is pinned (reference file:line in brackets):
                               [MASTestFunctions.py:72-385, RISETestFunctions.py:51-237,
                                AICTestFunctions.py:51-225, PosNegPertFunctions.py:31-175,
                                MonotonicityTest.py:51-213]
+  vit_mini.npz                hooked mini-ViT: pixel IG + attention-space IG (Baselines.IG)
+                              [VIT_LRP/ViT_ig.py:57-253, VIT_LRP/ViT_explanation_generator.py:139-386]
   sweep_small.npz             the 10-key Counter of run_perturbation, driven exactly like
                               XAI_Survey/evaluations/evaluatePerturbation.py:448-497
 The only stub is an inert `cvxopt` module (used by the reference only under
@@ -310,6 +312,34 @@ def sweep_fixture():
     print("sweep_small.npz", dict(zip(KEYS, out["counter_sum"])))
 
 
+def vit_fixture():
+    """Mini hooked ViT of the reference (ViT_ig.py:161-253; 32x32 image, patch 8, dim 32, depth 2,
+    4 heads, 10 classes): pixel-space IG through saliencyMethods.IG and attention-space IG through
+    Baselines.IG (ViT_explanation_generator.py:358-386)."""
+    from functools import partial
+    from util.attribution_methods.VIT_LRP.ViT_ig import VisionTransformer
+    from util.attribution_methods.VIT_LRP.ViT_explanation_generator import Baselines
+    torch.manual_seed(77)
+    model = VisionTransformer(img_size=32, patch_size=8, embed_dim=32, depth=2, num_heads=4, num_classes=10, mlp_ratio=4,
+                              qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6)).eval()
+    with torch.no_grad():                       # spread the logits a little (default init is nearly uniform)
+        for p in model.parameters():
+            p.mul_(3.0)
+    x = randn(78, 1, 3, 32, 32)
+    with torch.no_grad():
+        target = model(x).argmax(1)[0]
+    out = dict(x=x.numpy(), target=np.int64(target.item()))
+    for k, v in model.state_dict().items():
+        out["w_" + k] = v.numpy().copy()
+    out["ig"] = attr.IG(x.clone(), model, 50, 25, 1, 0, "cpu", target).detach().numpy()
+    b = Baselines(model)
+    out["attn_ig"] = b.IG(x.clone(), target, steps=20, device="cpu").detach().numpy()
+    out["raw_attn"] = b.generate_raw_attn(x.clone(), "cpu").detach().numpy()
+    out["attn_grad"] = b.generate_grad(x.clone(), target, "cpu").detach().numpy()
+    np.savez(os.path.join(HERE, "vit_mini.npz"), **out)
+    print("vit_mini.npz", {k: v.shape for k, v in out.items() if not k.startswith("w_")})
+
+
 KEYS = ["MAS_ins", "MAS_del", "RISE_ins", "RISE_del", "AIC_ins", "AIC_del", "LERF_res", "MORF_res", "MONO_pos", "MONO_neg"]
 
 
@@ -321,3 +351,4 @@ if __name__ == "__main__":
     perturb_fixture("perturb_patch.npz", 32, 32, 310, 50, patch=8)  # 16 patches, batch clamps to n_steps
     perturb_fixture("perturb_224.npz", 224, 224, 320, 50, keep_images=False, blur_k=(31, 31))
     sweep_fixture()
+    vit_fixture()

@@ -43,7 +43,7 @@ def test_ctypes_table_matches_header_and_library_loads():
     lib = _lib.load()
     assert lib.xai_version() == 1
     assert b"NULL" in lib.xai_strerror(-1) and lib.xai_strerror(0) == b"success"
-    assert lib.xai_rank_workspace_bytes(2, 50176) == 2 * 50176 * 16
+    assert lib.xai_rank_workspace_bytes(2, 50176) == 2 * (4 * 50176 + 5 * 256 * 49 + 8) * 4      # keys+idx ping-pong, 4 hists + offs, flags
     # argument validation happens before any HIP call, so it is checkable without a GPU
     assert lib.xai_ig_interp_f32(None, None, 0.0, None, 0, 1, 1, 4, None, None) == -1
     assert lib.xai_rank_f32(None, 1, 4, None, None, None, 0, None) == -1

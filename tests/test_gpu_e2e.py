@@ -278,3 +278,25 @@ def test_sweep_images_single_rank_and_csv(tmp_path):
     rows = [r.split(",") for r in open(path).read().strip().splitlines()]
     assert [r[0] for r in rows] == list(KEYS) + ["Attr Avg Runtime", "Total Runtime"]
     assert abs(float(rows[0][1]) - total["MAS_ins"] / 3) < 1e-12
+
+
+# ------------------------------------------------------------------------------ config 4: hooked ViT
+def test_vit_pixel_ig_and_attention_ig(attr):
+    from helpers import vit_mini_from
+    from xai_engine.vit_attr import Baselines
+    from oracle import ig as oig
+    from oracle import vit_attr as ovit
+    g = load_golden("vit_mini.npz")
+    model = vit_mini_from(g, DEV)
+    x = torch.from_numpy(g["x"])
+    t = torch.tensor(int(g["target"]))
+    got = attr.IG(x.clone(), model, 50, 25, 1, 0, DEV, t).cpu().numpy()
+    assert rel_inf(got, oig.ig(g["x"], model, 50, 25, 1, 0, int(t))) <= 1e-5
+    assert rel_inf(got, g["ig"]) <= 1e-4                       # smooth network (GELU/softmax): no gate flips
+    b = Baselines(model)
+    a = b.IG(x.clone(), t, steps=20, device=DEV).cpu().numpy()
+    assert a.shape == (1, 4, 4)
+    assert rel_inf(a, ovit.attention_ig(model, g["x"], int(t), 20)) <= 1e-5
+    assert rel_inf(a, g["attn_ig"]) <= 1e-4
+    assert rel_inf(b.generate_raw_attn(x, DEV).cpu().numpy(), g["raw_attn"]) <= 1e-4
+    assert rel_inf(b.generate_grad(x.clone(), t, DEV).cpu().numpy(), g["attn_grad"]) <= 1e-4

@@ -221,3 +221,13 @@ def test_rise_upsample_formula_equals_scipy_zoom():
     grid, shifts, cell = orise.draw_grid_and_shifts((30, 45), 3, 7, 0.5, rng)
     for gi in grid:
         assert np.abs(orise.upsample_grid(gi, 8 * cell) - orise.upsample_grid_formula(gi, 8 * cell)).max() <= 1e-6
+
+
+def test_vit_mini_pixel_ig_and_attention_ig():
+    """config 4: the reference's hooked ViT (rebuilt from its state dict) through the oracle."""
+    from helpers import vit_mini_from
+    from oracle import vit_attr
+    g = load_golden("vit_mini.npz")
+    model = vit_mini_from(g)
+    assert rel_inf(oig.ig(g["x"], model, 50, 25, 1, 0, int(g["target"])), g["ig"]) <= 1e-5
+    assert rel_inf(vit_attr.attention_ig(model, g["x"], int(g["target"]), 20), g["attn_ig"]) <= 1e-5
