@@ -21,22 +21,33 @@ __global__ __launch_bounds__(kWaves* kWave) void gradcam_kernel(const float* __r
   float acc[PPL];
 #pragma unroll
   for (int k = 0; k < PPL; ++k) acc[k] = 0.f;
-  for (int c = wave; c < C; c += kWaves) {
-    const float* g = grad + img + static_cast<int64_t>(c) * hw;
-    const float* a = act + img + static_cast<int64_t>(c) * hw;
-    float gv[PPL], av[PPL];
-    float s = 0.f;
+  // UC channels per trip: 2*UC*PPL independent loads are in flight before the first shuffle
+  // reduction (the kernel is latency-bound: one image is 0.8 MB)
+  constexpr int UC = PPL <= 2 ? 8 : (PPL <= 4 ? 4 : 2);
+  for (int c0 = wave; c0 < C; c0 += kWaves * UC) {
+    float gv[UC][PPL], av[UC][PPL];
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) {
-      const int p = lane + 64 * k;
-      gv[k] = p < hw ? g[p] : 0.f;
-      av[k] = p < hw ? a[p] : 0.f;
+    for (int u = 0; u < UC; ++u) {
+      const int c = c0 + u * kWaves;
+      const float* g = grad + img + static_cast<int64_t>(c) * hw;
+      const float* a = act + img + static_cast<int64_t>(c) * hw;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const int p = lane + 64 * k;
+        const bool ok = c < C && p < hw;
+        gv[u][k] = ok ? g[p] : 0.f;
+        av[u][k] = ok ? a[p] : 0.f;
+      }
     }
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) s += gv[k];
-    const float w = wave_sum(s) / n;
+    for (int u = 0; u < UC; ++u) {                      // channel order per wave stays ascending
+      float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < PPL; ++k) acc[k] += w * av[k];
+      for (int k = 0; k < PPL; ++k) s += gv[u][k];
+      const float w = wave_sum(s) / n;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) acc[k] += w * av[u][k];
+    }
   }
 #pragma unroll
   for (int k = 0; k < PPL; ++k) {

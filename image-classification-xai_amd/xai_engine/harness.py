@@ -1,0 +1,129 @@
+"""Dataset-facing side of the harness counterpart (reference
+XAI_Survey/evaluations/evaluatePerturbation.py: evaluate_perturbation :499-620, main :622-751).
+
+Formats kept from the reference:
+  * images `ILSVRC2012_val_XXXXXXXX.JPEG` in one directory, visited in sorted order (:520);
+    the validation index is `int(name.split("_")[2].split(".")[0]) - 1` (:528);
+  * `correctly_classified_<MODEL>.txt`: 50 000 lines of 0/1 indexed by that number (:507,:530);
+  * transform = Resize(img_hw) -> CenterCrop(img_hw) -> ToTensor, then Normalize (:680-694) -- done
+    with PIL exactly as torchvision does for PIL inputs (torchvision itself is not required);
+  * output `pert_test_results/<model>/<attr>_<count>_images.csv`, rows `key,mean` (:606-618).
+
+The order-dependent image filters (:530,:540,:569,:573-576) are run as a deterministic
+selection pre-pass (`select_images`) that every rank executes identically, so the image list --
+and therefore the result -- does not depend on the number of GPUs; the selected images are
+then sharded round-robin (`sweep.sweep_images`) and reduced with one all-reduce.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import sweep as _sweep
+from .blur import GaussianBlur
+from .ig import hip_device, _logits_of
+
+CNN_MEAN, CNN_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # evaluatePerturbation.py:683
+VIT_MEAN, VIT_STD = (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)                      # :686
+
+
+def load_image(path, img_hw):
+    """PIL image -> float32 (C, h, w) in [0,1]: Resize(img_hw) (shorter side, bilinear, PIL's
+    antialiasing), CenterCrop(img_hw), ToTensor.  Grey-scale files come back with C == 1 and are
+    rejected by the caller's shape test, as in the reference (:540)."""
+    from PIL import Image
+    img = Image.open(path)
+    w, h = img.size
+    short, long_ = (w, h) if w <= h else (h, w)
+    new_short, new_long = img_hw, int(img_hw * long_ / short)
+    nw, nh = (new_short, new_long) if w <= h else (new_long, new_short)
+    if (w, h) != (nw, nh):
+        img = img.resize((nw, nh), Image.BILINEAR)
+    left, top = int(round((nw - img_hw) / 2.0)), int(round((nh - img_hw) / 2.0))
+    img = img.crop((left, top, left + img_hw, top + img_hw))
+    arr = np.array(img)                                   # writable copy
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    return torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).float().div(255)
+
+
+def normalize(t, mean, std):
+    m = torch.tensor(mean, dtype=t.dtype).view(-1, 1, 1)
+    s = torch.tensor(std, dtype=t.dtype).view(-1, 1, 1)
+    return (t - m) / s
+
+
+def image_number(name):
+    """0-based validation index from `ILSVRC2012_val_00000123.JPEG` (:528)."""
+    return int((name.split("_")[2]).split(".")[0]) - 1
+
+
+def _pred(model, x, dev, cls=None):
+    """(class, softmax probability of that class) like get_classifier_pred (:76-80)."""
+    with torch.no_grad():
+        out = _logits_of(model(x.to(dev)))
+    c = int(out.argmax(1)[0]) if cls is None else cls
+    return c, float(torch.softmax(out, 1)[0, c])
+
+
+def select_images(testing_dict, correctly_classified=None, names=None):
+    """Deterministic pre-pass reproducing the reference's in-loop filters, in its order:
+    bitmap (:530) -> RGB shape (:540) -> blur/black sanity (:569) -> per-class quota (:573-576),
+    stopping at `image_count`.  Returns a list of (file name, normalised (1,3,H,W) CPU tensor, class)."""
+    dev = hip_device(testing_dict["device"])
+    model = testing_dict["models"][0]
+    root = testing_dict["imagenet_dataset"]
+    img_hw = testing_dict["img_hw"]
+    mean, std = testing_dict.get("normalize", (CNN_MEAN, CNN_STD))
+    count = testing_dict["image_count"]
+    num_classes = testing_dict.get("num_classes", 1000)
+    per_class = int(np.ceil(count / num_classes))
+    used = [0] * num_classes
+    blur = GaussianBlur(31, 31, dev)
+    chosen = []
+    for name in (names if names is not None else sorted(os.listdir(root))):
+        if len(chosen) == count:
+            break
+        if correctly_classified is not None and correctly_classified[image_number(name)] == 0:
+            continue
+        trans = load_image(os.path.join(root, name), img_hw)
+        if tuple(trans.shape) != (3, img_hw, img_hw):
+            continue
+        x = normalize(trans, mean, std).unsqueeze(0)
+        target, p_orig = _pred(model, x, dev)
+        blur_cls, p_blur = _pred(model, blur(x), dev)          # each substrate's OWN top class and its probability (:563-566)
+        black_cls, p_black = _pred(model, torch.zeros_like(x), dev)
+        if p_blur >= p_orig or p_black >= p_orig or target == black_cls or target == blur_cls:
+            continue
+        if used[target] == per_class:
+            continue
+        used[target] += 1
+        chosen.append((name, x, target))
+    return chosen
+
+
+def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pert_test_results"):
+    """Selection pre-pass, attribution + ten metrics per selected image (sharded over ranks), CSV on
+    rank 0.  `testing_dict` has the reference's keys (:705-718): models, imagenet_dataset, img_hw,
+    batch_size, attr_func, model_name, image_count, device (+ optional normalize=(mean, std),
+    class_map_path)."""
+    t_start = time.time()
+    cc = None
+    path = testing_dict.get("class_map_path")
+    if path:
+        cc = np.loadtxt(path).astype(np.int64)
+    chosen = select_images(testing_dict, cc)
+    model = testing_dict["models"][0]
+    dev = hip_device(testing_dict["device"])
+
+    def attr_fn(x, target):
+        return _sweep.get_CNN_attr(x, None, target, testing_dict)
+
+    total, used, attr_time = _sweep.sweep_images([c[1] for c in chosen], model, dev, attr_fn, img_hw=testing_dict["img_hw"],
+                                                 batch_size=testing_dict["batch_size"], fused=fused, rank=rank, world=world,
+                                                 testing_dict=testing_dict)
+    if rank == 0 and used:
+        name = f'{testing_dict["attr_func"]}_{testing_dict["image_count"]}_images.csv'
+        _sweep.write_csv(os.path.join(out_dir, testing_dict["model_name"], name), total, used, attr_time, time.time() - t_start)
+    return total, used, [c[0] for c in chosen]

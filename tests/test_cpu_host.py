@@ -195,3 +195,22 @@ def test_two_rank_gloo_sharding_and_reduction(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_harness_image_loading_and_name_parsing(tmp_path):
+    from PIL import Image
+    from xai_engine import harness
+    assert harness.image_number("ILSVRC2012_val_00000123.JPEG") == 122
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)          # landscape: shorter side 300 -> 224
+    Image.fromarray(arr).save(tmp_path / "a.png")
+    t = harness.load_image(str(tmp_path / "a.png"), 224)
+    assert t.shape == (3, 224, 224) and t.dtype == torch.float32 and 0 <= float(t.min()) and float(t.max()) <= 1
+    want = Image.fromarray(arr).resize((int(224 * 400 / 300), 224), Image.BILINEAR)
+    left = int(round((want.size[0] - 224) / 2.0))
+    want = np.asarray(want.crop((left, 0, left + 224, 224)), dtype=np.float32).transpose(2, 0, 1) / 255
+    np.testing.assert_array_equal(t.numpy(), want)
+    Image.fromarray(arr[:, :, 0]).save(tmp_path / "g.png")             # grey-scale -> 1 channel -> rejected by callers
+    assert harness.load_image(str(tmp_path / "g.png"), 224).shape == (1, 224, 224)
+    n = harness.normalize(t, harness.CNN_MEAN, harness.CNN_STD)
+    assert abs(float(n[0, 0, 0]) - (float(t[0, 0, 0]) - 0.485) / 0.229) < 1e-6

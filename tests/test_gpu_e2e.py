@@ -300,3 +300,47 @@ def test_vit_pixel_ig_and_attention_ig(attr):
     assert rel_inf(a, g["attn_ig"]) <= 1e-4
     assert rel_inf(b.generate_raw_attn(x, DEV).cpu().numpy(), g["raw_attn"]) <= 1e-4
     assert rel_inf(b.generate_grad(x.clone(), t, DEV).cpu().numpy(), g["attn_grad"]) <= 1e-4
+
+
+def test_evaluate_perturbation_on_a_directory(tmp_path):
+    """Dataset-facing harness: sorted file order, bitmap filter, RGB filter, sanity filter, per-class
+    quota, CSV -- and the same numbers as driving the pieces by hand."""
+    from PIL import Image
+    from xai_engine import harness
+    from xai_engine.sweep import KEYS, PerturbationSweep, get_CNN_attr
+    g = load_golden("sweep_small.npz")
+    model = tiny_from(g, DEV)
+    root = tmp_path / "val"
+    root.mkdir()
+    rng = np.random.default_rng(5)
+    n_files = 40
+    for i in range(1, n_files + 1):                                      # blocky colour images: some pass the sanity filter
+        blocks = rng.integers(0, 256, (4, 4, 3), dtype=np.uint8)
+        arr = np.kron(blocks, np.ones((12, 16, 1), dtype=np.uint8))          # 48 x 64 -> Resize(32) -> CenterCrop(32)
+        arr = np.clip(arr.astype(np.int32) + rng.integers(-40, 40, arr.shape), 0, 255).astype(np.uint8)
+        if i == 3:
+            arr = arr[:, :, 0]                                              # grey-scale file
+        Image.fromarray(arr).save(root / f"ILSVRC2012_val_{i:08d}.JPEG", format="PNG")
+    bitmap = np.ones(50, dtype=np.int64); bitmap[1] = 0                     # image #2 is "misclassified"
+    cmap = tmp_path / "correctly_classified_T.txt"
+    np.savetxt(cmap, bitmap, fmt="%d")
+    td = {"models": [model, model], "imagenet_dataset": str(root), "img_hw": 32, "batch_size": 50, "attr_func": "ig",
+          "model_name": "T", "image_count": 4, "device": DEV, "num_classes": 10, "class_map_path": str(cmap)}
+    total, used, names = harness.evaluate_perturbation(td, out_dir=str(tmp_path / "pert_test_results"))
+    assert 1 <= used <= 4 and names == sorted(names)
+    assert "ILSVRC2012_val_00000002.JPEG" not in names and "ILSVRC2012_val_00000003.JPEG" not in names
+    # by hand: the same selection list, attribution and fused sweep
+    chosen = harness.select_images(td, bitmap)
+    assert [c[0] for c in chosen] == names
+    classes = [c[2] for c in chosen]
+    assert max(classes.count(c) for c in set(classes)) <= int(np.ceil(4 / 10))          # one image per class
+    sw = PerturbationSweep(model, 32, DEV, batch_size=50)
+    want = {k: 0.0 for k in KEYS}
+    for _, x, t in chosen:
+        c = sw.run(x, get_CNN_attr(x, None, torch.tensor(t), td))
+        for k in KEYS:
+            want[k] += float(c[k])
+    for k in KEYS:
+        assert abs(total[k] - want[k]) <= 1e-9, k
+    rows = open(tmp_path / "pert_test_results" / "T" / "ig_4_images.csv").read().strip().splitlines()
+    assert len(rows) == 12 and rows[0].startswith("MAS_ins,") and rows[-1].startswith("Total Runtime,")
