@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void ig_accum_kernel(const float* __restric
 //     5.3 TB/s for the lane-strided mapping on 32 x 50 x 3x224x224);
 //   * ITEMS*C independent nt loads in flight per lane and step.
 // Per (pixel, channel) the sum still runs over s ascending in fp32: bit-identical to ig_accum_kernel.
-template <int BLOCK, int ITEMS, int C, bool WEIGHTED>
+template <int BLOCK, int ITEMS, int SU, int C, bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK) void ig_accum_stream_kernel(const float* __restrict__ grads, int n_steps,
                                                                 const int32_t* __restrict__ n_use_dev, int n_use_host,
                                                                 const float* __restrict__ w1, const float* __restrict__ w2,
@@ -198,18 +198,36 @@ __global__ __launch_bounds__(BLOCK) void ig_accum_stream_kernel(const float* __r
 #pragma unroll
       for (int c = 0; c < C; ++c) acc[i][c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // common prefix: no predicates, ITEMS*C loads issued back to back
-    for (int s = 0; s < n_min; ++s) {
-      float4 v[ITEMS][C];
+    // common prefix: no predicates, SU*ITEMS*C loads issued back to back, added in step order
+    int s = 0;
+    for (; s + SU <= n_min; s += SU) {
+      float4 v[SU][ITEMS][C];
 #pragma unroll
-      for (int i = 0; i < ITEMS; ++i)
+      for (int u = 0; u < SU; ++u)
 #pragma unroll
-        for (int c = 0; c < C; ++c) v[i][c] = V::load_nt(gp[i] + s * row + c * hw);
+        for (int i = 0; i < ITEMS; ++i)
+#pragma unroll
+          for (int c = 0; c < C; ++c) v[u][i][c] = V::load_nt(gp[i] + (s + u) * row + c * hw);
+#pragma unroll
+      for (int u = 0; u < SU; ++u)
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            float4 t = v[u][i][c];
+            if (WEIGHTED) {
+              t = vmul(t, V::splat(wa[i][s + u]));
+              if (wb[i]) t = vmul(t, V::splat(wb[i][s + u]));
+            }
+            acc[i][c] = vadd(acc[i][c], t);
+          }
+    }
+    for (; s < n_min; ++s) {
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          float4 t = v[i][c];
+          float4 t = V::load_nt(gp[i] + s * row + c * hw);
           if (WEIGHTED) {
             t = vmul(t, V::splat(wa[i][s]));
             if (wb[i]) t = vmul(t, V::splat(wb[i][s]));
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void ig_accum_stream_kernel(const float* __r
         }
     }
     // ragged tail: only when the lane's items straddle images with different Left-IG cutoffs
-    for (int s = n_min; s < n_max; ++s) {
+    for (s = n_min; s < n_max; ++s) {
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i)
         if (s < nu[i]) {
@@ -373,12 +391,19 @@ XAI_EXPORT int xai_ig_interp_f32(const float* x, const float* baseline, float ba
   XAI_REQUIRE(n_img > 0 && n_alpha > 0 && n_elem > 0 && alpha_img_stride >= 0, XAI_E_SHAPE);
   XAI_REQUIRE(n_img <= 65535, XAI_E_UNSUPPORTED);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // enough step chunks that even one image fills the chip (>= ~1000 workgroups)
+  // two step rows per lane: on this part HBM writes like MANY concurrent row streams (5.98 TB/s at 2 rows per
+  // lane vs 5.42 TB/s at 50, tune/tune_write.hip); x and b re-reads hit L2
   const bool vec = can_vec4(n_elem, {x, baseline, out});
   const int64_t tiles = xai_ceil_div(n_elem, kBlock * (vec ? 4 : 1));
-  int chunks = static_cast<int>(std::min<int64_t>(n_alpha, std::max<int64_t>(1, xai_ceil_div(2048, tiles * n_img))));
-  const int per = static_cast<int>(xai_ceil_div(n_alpha, chunks));
+  int per, chunks;
+  if (static_cast<int64_t>(n_img) * n_alpha * n_elem * 4 >= (int64_t(256) << 20)) {
+    per = n_alpha >= 2 ? 2 : 1;                                   // HBM-sized output: many short streams
+  } else {                                                        // cache-sized output: just enough workgroups to fill the chip
+    const int c0 = static_cast<int>(std::min<int64_t>(n_alpha, std::max<int64_t>(1, xai_ceil_div(2048, tiles * n_img))));
+    per = static_cast<int>(xai_ceil_div(n_alpha, c0));
+  }
   chunks = static_cast<int>(xai_ceil_div(n_alpha, per));
+  XAI_REQUIRE(chunks <= 65535, XAI_E_UNSUPPORTED);
   dim3 grid(static_cast<unsigned>(tiles), chunks, n_img);
   if (vec)
     hipLaunchKernelGGL(ig_interp_kernel<4>, grid, dim3(kBlock), 0, st, x, baseline, baseline_scalar, alphas, alpha_img_stride, n_alpha, n_elem, per, out);
@@ -412,12 +437,13 @@ XAI_EXPORT int xai_ig_accum_f32(const float* grads, int n_img, int n_steps, cons
     const int64_t items = static_cast<int64_t>(n_img) * (hw / 4);
     const int cus = xai_cu_count();
     const bool big = items >= static_cast<int64_t>(cus) * 2 * 256 * 2;
-#define XAI_STREAM(BLK, IT, CC, WT, GRID) \
-  hipLaunchKernelGGL((ig_accum_stream_kernel<BLK, IT, CC, WT>), dim3(GRID), dim3(BLK), 0, st, grads, n_steps, n_use_dev, n_use_host, \
+#define XAI_STREAM(BLK, IT, SU, CC, WT, GRID) \
+  hipLaunchKernelGGL((ig_accum_stream_kernel<BLK, IT, SU, CC, WT>), dim3(GRID), dim3(BLK), 0, st, grads, n_steps, n_use_dev, n_use_host, \
                      step_w1, step_w2, x, baseline, baseline_scalar, hw, n_img, out_chw, out_abs_hw)
+  // small (cache-resident, latency-bound) problems: few lanes, so each keeps 5 steps x C loads in flight
 #define XAI_STREAM_C(CC, WT) \
-  do { if (big) XAI_STREAM(256, 4, CC, WT, static_cast<unsigned>(cus * 2)); \
-       else XAI_STREAM(64, 1, CC, WT, static_cast<unsigned>(xai_ceil_div(items, 64))); } while (0)
+  do { if (big) XAI_STREAM(256, 4, 1, CC, WT, static_cast<unsigned>(cus * 2)); \
+       else XAI_STREAM(64, 1, 5, CC, WT, static_cast<unsigned>(xai_ceil_div(items, 64))); } while (0)
     if (C == 3) { if (step_w1) XAI_STREAM_C(3, true); else XAI_STREAM_C(3, false); }
     else        { if (step_w1) XAI_STREAM_C(1, true); else XAI_STREAM_C(1, false); }
 #undef XAI_STREAM_C
