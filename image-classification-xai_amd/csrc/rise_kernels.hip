@@ -31,13 +31,15 @@ __device__ __forceinline__ Tap make_tap(int j, int n_in, int n_out) {
   return Tap{i0, i1, static_cast<float>(c - i0)};
 }
 
-__device__ __forceinline__ float blend(const uint8_t* g, int s, const Tap& r, const Tap& c) {
+// lo/hi = min/max of the mask's grid: skimage.transform.resize clips its output to the input range
+// (clip=True), which also absorbs the last-bit overshoot of the fp32 blend
+__device__ __forceinline__ float blend(const uint8_t* g, int s, const Tap& r, const Tap& c, float lo, float hi) {
   const float wr0 = 1.f - r.t, wr1 = r.t, wc0 = 1.f - c.t, wc1 = c.t;
   float v = g[r.i0 * s + c.i0] ? wr0 * wc0 : 0.f;
   v += g[r.i0 * s + c.i1] ? wr0 * wc1 : 0.f;
   v += g[r.i1 * s + c.i0] ? wr1 * wc0 : 0.f;
   v += g[r.i1 * s + c.i1] ? wr1 * wc1 : 0.f;
-  return v;
+  return fminf(fmaxf(v, lo), hi);
 }
 
 __global__ __launch_bounds__(kBlock) void rise_apply_kernel(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift, int s,
@@ -45,7 +47,14 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel(const uint8_t* __res
                                                             int W, float* __restrict__ masked, float* __restrict__ masks) {
   extern __shared__ uint8_t g[];                        // [s][s]
   const int n = blockIdx.y;
-  for (int i = threadIdx.x; i < s * s; i += kBlock) g[i] = grid[static_cast<int64_t>(n) * s * s + i];
+  int one = 0, zero = 0;
+  for (int i = threadIdx.x; i < s * s; i += kBlock) {
+    const uint8_t b = grid[static_cast<int64_t>(n) * s * s + i];
+    g[i] = b;
+    one |= (b != 0); zero |= (b == 0);
+  }
+  const float hi = __syncthreads_or(one) ? 1.f : 0.f;
+  const float lo = __syncthreads_or(zero) ? 0.f : 1.f;
   __syncthreads();
   const int64_t hw = static_cast<int64_t>(H) * W;
   const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -54,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel(const uint8_t* __res
   const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
   const Tap tr = make_tap(y + shift[2 * n], s, up_h);
   const Tap tc = make_tap(x + shift[2 * n + 1], s, up_w);
-  const float m = blend(g, s, tr, tc);
+  const float m = blend(g, s, tr, tc, lo, hi);
   if (masks) masks[static_cast<int64_t>(n) * hw + p] = m;
   if (masked) {
     float* o = masked + static_cast<int64_t>(n) * C * hw + p;
@@ -68,7 +77,14 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel_v4(const uint8_t* __
                                                                int H, int W, float* __restrict__ masked, float* __restrict__ masks) {
   extern __shared__ uint8_t g[];
   const int n = blockIdx.y;
-  for (int i = threadIdx.x; i < s * s; i += kBlock) g[i] = grid[static_cast<int64_t>(n) * s * s + i];
+  int one = 0, zero = 0;
+  for (int i = threadIdx.x; i < s * s; i += kBlock) {
+    const uint8_t b = grid[static_cast<int64_t>(n) * s * s + i];
+    g[i] = b;
+    one |= (b != 0); zero |= (b == 0);
+  }
+  const float hi = __syncthreads_or(one) ? 1.f : 0.f;
+  const float lo = __syncthreads_or(zero) ? 0.f : 1.f;
   __syncthreads();
   const int64_t hw = static_cast<int64_t>(H) * W;
   const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
@@ -78,10 +94,10 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel_v4(const uint8_t* __
   const int sx = shift[2 * n + 1];
   const Tap tr = make_tap(y + shift[2 * n], s, up_h);
   float4 m;
-  m.x = blend(g, s, tr, make_tap(x + sx, s, up_w));
-  m.y = blend(g, s, tr, make_tap(x + 1 + sx, s, up_w));
-  m.z = blend(g, s, tr, make_tap(x + 2 + sx, s, up_w));
-  m.w = blend(g, s, tr, make_tap(x + 3 + sx, s, up_w));
+  m.x = blend(g, s, tr, make_tap(x + sx, s, up_w), lo, hi);
+  m.y = blend(g, s, tr, make_tap(x + 1 + sx, s, up_w), lo, hi);
+  m.z = blend(g, s, tr, make_tap(x + 2 + sx, s, up_w), lo, hi);
+  m.w = blend(g, s, tr, make_tap(x + 3 + sx, s, up_w), lo, hi);
   if (masks) st4(masks + static_cast<int64_t>(n) * hw + p, m);
   if (masked) {
     float* o = masked + static_cast<int64_t>(n) * C * hw + p;
@@ -104,7 +120,8 @@ __global__ __launch_bounds__(kBlock) void rise_accum_kernel(const uint8_t* __res
   Tap* ctap = rtap + up_h;                                          // [up_w]
   float* sc = reinterpret_cast<float*>(ctap + up_w);                // [kStage]
   int* sh = reinterpret_cast<int*>(sc + kStage);                    // [kStage][2]
-  uint8_t* gs = reinterpret_cast<uint8_t*>(sh + 2 * kStage);        // [kStage][s*s]
+  float* lim = reinterpret_cast<float*>(sh + 2 * kStage);           // [kStage][2] clip range of each mask
+  uint8_t* gs = reinterpret_cast<uint8_t*>(lim + 2 * kStage);       // [kStage][s*s]
   for (int i = threadIdx.x; i < up_h; i += kBlock) rtap[i] = make_tap(i, s, up_h);
   for (int i = threadIdx.x; i < up_w; i += kBlock) ctap[i] = make_tap(i, s, up_w);
   const int64_t hw = static_cast<int64_t>(H) * W;
@@ -124,11 +141,18 @@ __global__ __launch_bounds__(kBlock) void rise_accum_kernel(const uint8_t* __res
     }
     for (int i = threadIdx.x; i < cnt * ss; i += kBlock) gs[i] = grid[static_cast<int64_t>(base) * ss + i];
     __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += kBlock) {
+      int one = 0, zero = 0;
+      for (int j = 0; j < ss; ++j) { one |= (gs[i * ss + j] != 0); zero |= (gs[i * ss + j] == 0); }
+      lim[2 * i] = zero ? 0.f : 1.f;
+      lim[2 * i + 1] = one ? 1.f : 0.f;
+    }
+    __syncthreads();
     if (live) {
       for (int m = 0; m < cnt; ++m) {
         const Tap tr = rtap[y + sh[2 * m]];
         const Tap tc = ctap[x + sh[2 * m + 1]];
-        acc += static_cast<double>(sc[m]) * static_cast<double>(blend(gs + m * ss, s, tr, tc));
+        acc += static_cast<double>(sc[m]) * static_cast<double>(blend(gs + m * ss, s, tr, tc, lim[2 * m], lim[2 * m + 1]));
       }
     }
   }
@@ -165,7 +189,7 @@ XAI_EXPORT int xai_rise_accum_f64(const uint8_t* grid, const int32_t* shift, con
   XAI_REQUIRE(n_masks > 0 && s > 0 && cell_h > 0 && cell_w > 0 && H > 0 && W > 0, XAI_E_SHAPE);
   XAI_REQUIRE(H + cell_h - 1 <= (s + 1) * cell_h && W + cell_w - 1 <= (s + 1) * cell_w, XAI_E_SHAPE);
   const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
-  const size_t lds = static_cast<size_t>(up_h + up_w) * sizeof(Tap) + kStage * (sizeof(float) + 2 * sizeof(int)) +
+  const size_t lds = static_cast<size_t>(up_h + up_w) * sizeof(Tap) + kStage * (3 * sizeof(float) + 2 * sizeof(int)) +
                      static_cast<size_t>(kStage) * s * s;
   XAI_REQUIRE(s <= 64 && lds <= 64 * 1024, XAI_E_UNSUPPORTED);
   const int64_t hw = static_cast<int64_t>(H) * W;

@@ -29,8 +29,10 @@ def draw_grid_and_shifts(input_size, N, s, p1, rng=np.random):
 
 
 def upsample_grid(g, up):
-    return ndimage.zoom(g.astype(F32), (up[0] / g.shape[0], up[1] / g.shape[1]), order=1,
-                        mode="mirror", grid_mode=True)
+    """skimage.transform.resize(g, up, order=1, mode='reflect', anti_aliasing=False): ndimage.zoom with the
+    'mirror' boundary on the half-pixel grid, then clipped to the input's value range (resize's clip=True)."""
+    out = ndimage.zoom(g.astype(F32), (up[0] / g.shape[0], up[1] / g.shape[1]), order=1, mode="mirror", grid_mode=True)
+    return np.clip(out, g.min(), g.max())
 
 
 def taps_1d(n_in, n_out):
@@ -54,7 +56,7 @@ def upsample_grid_formula(g, up):
     wc0, wc1 = (1 - tc)[None, :], tc[None, :]
     out = (g[r0][:, c0] * (wr0 * wc0) + g[r0][:, c1] * (wr0 * wc1)
            + g[r1][:, c0] * (wr1 * wc0) + g[r1][:, c1] * (wr1 * wc1))
-    return out.astype(F32)
+    return np.clip(out, g.min(), g.max()).astype(F32)
 
 
 def masks_from(grid, shifts, input_size, cell):

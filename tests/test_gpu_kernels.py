@@ -348,3 +348,67 @@ def test_abi_argument_errors(K):
     assert lib.xai_ig_interp_f32(x.data_ptr(), None, 0.0, x.data_ptr(), 0, 0, 1, 4, x.data_ptr(), None) == -2
     assert lib.xai_gradcam_f32(x.data_ptr(), x.data_ptr(), 1, 1, 64, 64, 1, x.data_ptr(), None) == -3
     assert lib.xai_blur_sep_f32(x.data_ptr(), x.data_ptr(), 4, 1, 1, 2, 2, x.data_ptr(), None) == -2
+
+
+# ------------------------------------------------------------------------------ f4 accumulators on K2's weighted form
+def test_tis_and_vitcx_accumulators(K):
+    from xai_engine.masked import tis_saliency, causal_saliency
+    rng = np.random.default_rng(20)
+    masks = (rng.random((1024, 196)) < 0.5).astype(np.float32)
+    scores = rng.random(1024).astype(np.float32)
+    got = tis_saliency(dev(scores), dev(masks)).cpu().numpy()
+    m64, s64 = masks.astype(np.float64), scores.astype(np.float64)
+    want = (s64[:, None] * m64).sum(0) / m64.sum(0)                      # TIS.py:337-356
+    assert rel_inf(got, want) <= 2e-6
+    fm = rng.random((130, 224 * 224)).astype(np.float32)                 # ViT-CX feature masks
+    p = rng.standard_normal(130).astype(np.float32)
+    got = causal_saliency(dev(p), dev(fm)).cpu().numpy()
+    f64 = fm.astype(np.float64)
+    want = p.astype(np.float64) @ (f64 / f64.sum(0)) / 130               # causal_score.py:57-60
+    assert rel_inf(got, want) <= 5e-6
+
+
+# ------------------------------------------------------------------------------ size-independent properties at full size
+def test_full_size_perturbation_properties(K):
+    """224x224, 224 steps, heavy ties (ReLU'd map): every step flips exactly `step` new pixels, the flipped
+    set is monotone, the last image is `finish`, ascending and descending orders are mirror images."""
+    H = W = 224
+    rng = np.random.default_rng(30)
+    sal = np.maximum(rng.standard_normal(H * W), 0).astype(np.float32)    # ~50 % exact zeros
+    start = rng.standard_normal((3, H, W)).astype(np.float32)
+    finish = start + 1.0
+    order, rk = K.rank(dev(sal[None]))
+    o = order.cpu().numpy()[0]
+    assert (np.diff(sal[o]) >= 0).all()                                   # sorted
+    tie = sal[o][:-1] == sal[o][1:]
+    assert (np.diff(o)[tie] > 0).all()                                    # stable: ties in index order
+    np.testing.assert_array_equal(np.sort(o), np.arange(H * W))           # a permutation
+    f_desc = K.flip_steps(rk[0], True, 224)
+    f_asc = K.flip_steps(rk[0], False, 224)
+    np.testing.assert_array_equal(f_desc.cpu().numpy() + f_asc.cpu().numpy(), 223)    # mirror images (HW = 224*224)
+    imgs = K.perturb_batch(dev(start), dev(finish), f_desc, 0, 224)
+    flipped = (imgs != dev(start)[None]).all(1).reshape(224, -1)          # (step, pixel)
+    counts = flipped.sum(1).cpu().numpy()
+    np.testing.assert_array_equal(counts, 224 * np.arange(1, 225))
+    assert bool((flipped[1:] | ~flipped[:-1]).all())                      # once flipped, stays flipped
+    np.testing.assert_array_equal(imgs[-1].cpu().numpy(), finish)
+    seg, total = K.segment_sums(dev(sal), order[0], True, 224, 224)
+    assert abs(float(seg.sum()) - float(total[0])) <= 1e-3 * float(total[0])
+
+
+def test_full_size_rise_properties(K):
+    """N = 8000 masks on 224x224: accumulation is linear in the scores and equals N*p1*scale for unit scores
+    up to the sampling noise of the masks' mean; mask values stay in [0, 1]."""
+    from xai_engine.rise import draw_masks
+    np.random.seed(0)
+    grid, shifts, cell = draw_masks((224, 224), 8000, 8, 0.5)
+    g8, sh = dev(grid), dev(shifts)
+    ones = torch.ones(8000, device=DEV)
+    a1 = K.rise_accum(g8, sh, ones, cell, 224, 224, 1.0 / 8000 / 0.5)
+    assert abs(float(a1.mean()) - 1.0) < 0.02                              # E[mask] = p1
+    s = torch.rand(8000, device=DEV)
+    a2 = K.rise_accum(g8, sh, s, cell, 224, 224, 1.0)
+    a3 = K.rise_accum(g8, sh, 2 * s + ones, cell, 224, 224, 1.0)
+    assert rel_inf(a3.cpu().numpy(), (2 * a2 + a1 * 8000 * 0.5).cpu().numpy()) <= 1e-6      # 2*s+1 itself rounds in fp32
+    m = K.rise_apply(g8[:64], sh[:64], cell, torch.ones(1, 224, 224, device=DEV), want_masked=False, want_masks=True)
+    assert float(m.min()) >= 0.0 and float(m.max()) <= 1.0
