@@ -18,7 +18,8 @@ __global__ __launch_bounds__(kBlock) void flip_steps_kernel(const int32_t* __res
   flip[p] = static_cast<int32_t>(pos / step_size);
 }
 
-// grid = (pixel tiles, step chunks)
+// grid = (pixel tiles, step chunks, channel groups): gridDim.z == 1 -> a lane handles all channels,
+// gridDim.z == C -> one channel per lane (more, shorter write streams for HBM-sized batches)
 template <int W>
 __global__ __launch_bounds__(kBlock) void perturb_kernel(const float* __restrict__ start, const float* __restrict__ finish,
                                                          const int32_t* __restrict__ flip, int C, int64_t hw, int first_step,
@@ -28,9 +29,10 @@ __global__ __launch_bounds__(kBlock) void perturb_kernel(const float* __restrict
   const int k0 = blockIdx.y * per_chunk;
   const int k1 = min(k0 + per_chunk, n_batch);
   const int64_t img = static_cast<int64_t>(C) * hw;
+  const int c_lo = gridDim.z == 1 ? 0 : blockIdx.z, c_hi = gridDim.z == 1 ? C : blockIdx.z + 1;
   if constexpr (W == 4) {
     const int4 f = *reinterpret_cast<const int4*>(flip + p);
-    for (int c = 0; c < C; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
       const float4 s = ld4(start + c * hw + p);
       const float4 e = ld4(finish + c * hw + p);
       float* o = out + k0 * img + c * hw + p;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void perturb_kernel(const float* __restrict
     }
   } else {
     const int f = flip[p];
-    for (int c = 0; c < C; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
       const float s = start[c * hw + p], e = finish[c * hw + p];
       float* o = out + k0 * img + c * hw + p;
       for (int k = k0; k < k1; ++k, o += img) *o = (f <= first_step + k) ? e : s;
@@ -149,10 +151,17 @@ XAI_EXPORT int xai_perturb_batch_f32(const float* start, const float* finish, co
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = (hw % 4 == 0) && xai_aligned16(start) && xai_aligned16(finish) && xai_aligned16(flip_step) && xai_aligned16(out);
   const int64_t tiles = xai_ceil_div(hw, kBlock * (vec ? 4 : 1));
-  int chunks = static_cast<int>(std::min<int64_t>(n_batch, std::max<int64_t>(1, xai_ceil_div(2048, tiles))));
-  const int per = static_cast<int>(xai_ceil_div(n_batch, chunks));
+  int per, chunks, zdim = 1;
+  if (static_cast<int64_t>(n_batch) * C * hw * 4 >= (int64_t(64) << 20) && C <= 64) {
+    per = n_batch >= 2 ? 2 : 1;                  // HBM-sized batch: one channel x two step images per lane
+    zdim = C;
+  } else {
+    const int c0 = static_cast<int>(std::min<int64_t>(n_batch, std::max<int64_t>(1, xai_ceil_div(2048, tiles))));
+    per = static_cast<int>(xai_ceil_div(n_batch, c0));
+  }
   chunks = static_cast<int>(xai_ceil_div(n_batch, per));
-  dim3 grid(static_cast<unsigned>(tiles), chunks);
+  XAI_REQUIRE(chunks <= 65535, XAI_E_UNSUPPORTED);
+  dim3 grid(static_cast<unsigned>(tiles), chunks, zdim);
   if (vec) hipLaunchKernelGGL(perturb_kernel<4>, grid, dim3(kBlock), 0, st, start, finish, flip_step, C, hw, first_step, n_batch, per, out);
   else     hipLaunchKernelGGL(perturb_kernel<1>, grid, dim3(kBlock), 0, st, start, finish, flip_step, C, hw, first_step, n_batch, per, out);
   return xai_launch_status();
