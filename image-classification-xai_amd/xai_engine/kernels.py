@@ -264,9 +264,11 @@ def blur_sep(x, k1d):
     return out
 
 
-def softmax_stats(logits, target=None, want_entropy=True, want_argmax=True):
+def softmax_stats(logits, target=None, want_entropy=True, want_argmax=True, out=None, offset=0):
     """logits (B,K); target: None (row argmax), int, or int32 device tensor (1,).
-    -> (p_target (B,), entropy_bits (B,) or None, argmax (B,) int32 or None)."""
+    -> (p_target (B,), entropy_bits (B,) or None, argmax (B,) int32 or None).
+    `out=(p, entropy, argmax)` (1-D fp32/fp32/int32 device tensors) writes rows [offset, offset+B) of
+    preallocated curves instead of allocating (the ins/del loop fills its curves in place)."""
     _need(logits, F32, "logits")
     B, K = logits.shape
     t_dev, t_host = None, -1
@@ -274,8 +276,20 @@ def softmax_stats(logits, target=None, want_entropy=True, want_argmax=True):
         t_dev = _need(target, I32, "target")
     elif target is not None:
         t_host = int(target)
-    p = torch.empty(B, dtype=F32, device=logits.device)
-    ent = torch.empty(B, dtype=F32, device=logits.device) if want_entropy else None
-    am = torch.empty(B, dtype=I32, device=logits.device) if want_argmax else None
+    if out is None:
+        p = torch.empty(B, dtype=F32, device=logits.device)
+        ent = torch.empty(B, dtype=F32, device=logits.device) if want_entropy else None
+        am = torch.empty(B, dtype=I32, device=logits.device) if want_argmax else None
+    else:
+        p, ent, am = out
+        _need(p, F32, "out p")
+        if ent is not None:
+            _need(ent, F32, "out entropy")
+        if am is not None:
+            _need(am, I32, "out argmax")
+        for t in (p, ent, am):
+            if t is not None and (t.dim() != 1 or offset < 0 or offset + B > t.numel()):
+                raise ValueError("out tensors must be 1-D with room for rows [offset, offset+B)")
+        p, ent, am = p[offset:offset + B], (None if ent is None else ent[offset:offset + B]), (None if am is None else am[offset:offset + B])
     _call("xai_softmax_stats_f32", logits.device, _ptr(logits), B, K, _ptr(t_dev), t_host, _ptr(p), _ptr(ent), _ptr(am))
     return p, ent, am

@@ -22,14 +22,14 @@ from .ig import hip_device, _logits_of
 class _Probe:
     """softmax statistics of one forward pass, kept on the device."""
 
-    def __init__(self, logits, target=None):
-        self.p, self.entropy, self.argmax = K.softmax_stats(logits.float().contiguous(), target)
+    def __init__(self, logits, target=None, out=None, offset=0):
+        self.p, self.entropy, self.argmax = K.softmax_stats(logits.float().contiguous(), target, out=out, offset=offset)
 
 
 def sequence_stats(stats, start, finish, flip, n_steps, batches, target, first):
-    """Run one insertion/deletion sequence on the device.  `stats(images, target) -> _Probe`;
-    start/finish (C,H,W); flip (H*W,) int32; `first` = the _Probe of curve point 0.
-    Returns device tensors p[target], entropy, argmax of length n_steps + 1."""
+    """Run one insertion/deletion sequence on the device.  `stats(images, target, out, offset) -> _Probe`
+    writes its rows straight into the curves; start/finish (C,H,W); flip (H*W,) int32; `first` = the _Probe
+    of curve point 0.  Returns device tensors p[target], entropy, argmax of length n_steps + 1."""
     dev = start.device
     p = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
     ent = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
@@ -41,8 +41,7 @@ def sequence_stats(stats, start, finish, flip, n_steps, batches, target, first):
         if b == 0:                                      # MonotonicityTest's empty remainder batch: nothing to add
             continue
         images = K.perturb_batch(start, finish, flip, done, b, out=buf[:b])
-        st = stats(images, target)
-        p[1 + done:1 + done + b], ent[1 + done:1 + done + b], am[1 + done:1 + done + b] = st.p, st.entropy, st.argmax
+        stats(images, target, (p, ent, am), 1 + done)
         done += b
     return p, ent, am
 
@@ -82,9 +81,9 @@ class _PerturbationMetric:
             self.step_size = step_size                      # the reference overwrites it too (:92)
         temp = 0.1 if clip_info is not None else None       # CLIP similarities are softmaxed at T = 0.1
 
-        def stats(images, target):
+        def stats(images, target, out=None, offset=0):
             lg = self._logits(images, clip_info)
-            return _Probe(lg / temp if temp else lg, target)
+            return _Probe(lg / temp if temp else lg, target, out, offset)
 
         img = img_tensor.to(dev, torch.float32).contiguous()
         substrate = self.substrate_fn(img_tensor).to(dev, torch.float32).contiguous()

@@ -102,9 +102,9 @@ class PerturbationSweep:
         self.batch_size = batch_size
         self.blur = GaussianBlur(klen, ksig, self.dev)
 
-    def _stats(self, images, target):
+    def _stats(self, images, target, out=None, offset=0):
         with torch.no_grad():
-            return _Probe(_logits_of(self.model(images)).detach(), target)
+            return _Probe(_logits_of(self.model(images)).detach(), target, out, offset)
 
     def run(self, input_tensor, attribution, return_curves=False):
         dev = self.dev
