@@ -28,7 +28,8 @@ SIGNATURES = {
     "xai_ig_finish_f32": [_p, _i, _i, _p, _p, _f, _i, _l, _p, _p, _p],
     "xai_sumsq_f32": [_p, _i, _l, _p, _p],
     "xai_idgi_accum_f32": [_p, _i, _p, _p, _l, _p, _p],
-    "xai_gradcam_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "xai_gradcam_workspace_bytes": [_i, _i, _i, _i],
+    "xai_gradcam_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p, C.c_size_t, _p],
     "xai_bilinear_up_f32": [_p, _i, _i, _i, _i, _i, _f, _i, _p, _p],
     "xai_rise_apply_f32": [_p, _p, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p],
     "xai_rise_accum_f64": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _d, _p, _p],
@@ -40,7 +41,7 @@ SIGNATURES = {
     "xai_blur_sep_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
     "xai_softmax_stats_f32": [_p, _i, _i, _p, _i, _p, _p, _p, _p],
 }
-_RESTYPE = {"xai_strerror": C.c_char_p, "xai_rank_workspace_bytes": C.c_size_t}
+_RESTYPE = {"xai_strerror": C.c_char_p, "xai_rank_workspace_bytes": C.c_size_t, "xai_gradcam_workspace_bytes": C.c_size_t}
 
 _lib = None
 

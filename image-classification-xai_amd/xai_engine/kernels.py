@@ -161,7 +161,9 @@ def gradcam(act, grad, relu=True):
         raise ValueError("act and grad must both be (B,C,h,w)")
     B, Cc, h, w = act.shape
     cam = torch.empty((B, h, w), dtype=F32, device=act.device)
-    _call("xai_gradcam_f32", act.device, _ptr(act), _ptr(grad), B, Cc, h, w, int(bool(relu)), _ptr(cam))
+    nbytes = _lib.load().xai_gradcam_workspace_bytes(B, Cc, h, w)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=act.device) if nbytes else None
+    _call("xai_gradcam_f32", act.device, _ptr(act), _ptr(grad), B, Cc, h, w, int(bool(relu)), _ptr(cam), _ptr(ws), nbytes)
     return cam
 
 

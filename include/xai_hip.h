@@ -98,9 +98,13 @@ int xai_idgi_accum_f32(const float* grads, int n_steps, const float* logits,
 
 /* K3a  w[c] = mean_hw grad[b][c]; cam[b][p] = (relu) sum_c w[c]*act[b][c][p]
  * replaces  captum 0.7.0 LayerGradCam.attribute as called at evaluatePerturbation.py:149-151
- *   act, grad : [B][C][h*w];  cam : [B][h*w];  h*w <= 1024 */
+ *   act, grad : [B][C][h*w];  cam : [B][h*w];  h*w <= 1024
+ *   ws : optional device scratch of xai_gradcam_workspace_bytes(B,C,h,w) bytes; with it the channels
+ *        of one image are reduced by several workgroups (partials summed in a fixed order);
+ *        NULL -> one workgroup per image */
+size_t xai_gradcam_workspace_bytes(int B, int C, int h, int w);
 int xai_gradcam_f32(const float* act, const float* grad, int B, int C, int h, int w, int relu,
-                    float* cam, xai_stream_t stream);
+                    float* cam, void* ws, size_t ws_bytes, xai_stream_t stream);
 
 /* K3b  bilinear up-sample, align_corners = False; dst = scale * up(src), |.| if take_abs
  * replaces  torchvision Resize((H,W), antialias=True) at evaluatePerturbation.py:153 and

@@ -52,7 +52,7 @@ def test_ctypes_table_matches_header_and_library_loads():
 def test_every_header_entry_cites_the_reference_line_it_replaces():
     src = open(HEADER).read()
     for name in _declared():
-        if name in ("xai_version", "xai_strerror", "xai_rank_workspace_bytes", "xai_flip_steps_i32", "xai_ig_finish_f32",
+        if name in ("xai_version", "xai_strerror", "xai_rank_workspace_bytes", "xai_gradcam_workspace_bytes", "xai_flip_steps_i32", "xai_ig_finish_f32",
                     "xai_idgi_accum_f32"):
             continue
         at = src.index(name + "(")

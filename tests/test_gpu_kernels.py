@@ -346,7 +346,7 @@ def test_abi_argument_errors(K):
     assert lib.xai_ig_interp_f32(None, None, 0.0, None, 0, 1, 1, 4, None, None) == -1
     x = torch.zeros(8, device=DEV)
     assert lib.xai_ig_interp_f32(x.data_ptr(), None, 0.0, x.data_ptr(), 0, 0, 1, 4, x.data_ptr(), None) == -2
-    assert lib.xai_gradcam_f32(x.data_ptr(), x.data_ptr(), 1, 1, 64, 64, 1, x.data_ptr(), None) == -3
+    assert lib.xai_gradcam_f32(x.data_ptr(), x.data_ptr(), 1, 1, 64, 64, 1, x.data_ptr(), None, 0, None) == -3
     assert lib.xai_blur_sep_f32(x.data_ptr(), x.data_ptr(), 4, 1, 1, 2, 2, x.data_ptr(), None) == -2
 
 
