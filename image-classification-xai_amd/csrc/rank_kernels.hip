@@ -2,7 +2,7 @@
 //
 // 8-bit digits, 4 passes over (key, index) pairs that ping-pong through an L2-resident scratch.
 // Work is tiled by 1024 keys (grid = tiles x maps, so one 224x224 map already spreads over 49 CUs
-// and a batch of maps over the whole chip); a sort is 1 memset + 9 launches:
+// and a batch of maps over the whole chip); a sort is 10 launches (zero-fill, hist, 4 x (scan, scatter)):
 //   hist    : (pass 0 only) per-tile digit histogram in LDS (ds_add) -> hist[0][tile][digit];
 //             the histograms of passes 1..3 are accumulated by the previous pass's scatter with
 //             global atomics on the DESTINATION tile (counts do not depend on arrival order)
@@ -57,6 +57,13 @@ __device__ __forceinline__ SegPtrs seg_ptrs(uint32_t* ws, int seg, int n_seg, in
   p.key[0] = b; p.key[1] = b + hw; p.idx[0] = b + 2 * hw; p.idx[1] = b + 3 * hw;
   p.offs = b + 4 * hw;
   return p;
+}
+
+// zero the front of the scratch (flags + histograms).  A kernel rather than hipMemsetAsync: a memset node
+// captured into a hipGraph did not take effect on replay (ROCm 7.2, tests/test_gpu_kernels.py graph test).
+__global__ __launch_bounds__(kBlock) void rank_zero_kernel(uint32_t* __restrict__ w, size_t n_words) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_words; i += stride) w[i] = 0u;
 }
 
 template <bool FIRST>
@@ -226,9 +233,9 @@ XAI_EXPORT int xai_rank_f32(const float* sal, int n_seg, int64_t hw, int32_t* or
   hipStream_t st = static_cast<hipStream_t>(stream);
   uint32_t* w = static_cast<uint32_t*>(ws);
   const int n_tiles = tiles_of(hw);
-  // zero the identity flags and the four histograms of every map (stream-ordered, capturable)
-  hipError_t e = hipMemsetAsync(w, 0, front_words(n_seg, n_tiles) * sizeof(uint32_t), st);
-  if (e != hipSuccess) return static_cast<int>(e);
+  // zero the identity flags and the four histograms of every map
+  const size_t fw = front_words(n_seg, n_tiles);
+  hipLaunchKernelGGL(rank_zero_kernel, dim3(static_cast<unsigned>(std::min<size_t>(1024, (fw + kBlock - 1) / kBlock))), dim3(kBlock), 0, st, w, fw);
   const dim3 grid(n_tiles, n_seg), blk(kBlock);
   hipLaunchKernelGGL(rank_hist_kernel<true>, grid, blk, 0, st, sal, hw, n_tiles, 0, w);
   for (int pass = 0; pass < 4; ++pass) {

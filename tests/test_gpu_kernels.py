@@ -412,3 +412,46 @@ def test_full_size_rise_properties(K):
     assert rel_inf(a3.cpu().numpy(), (2 * a2 + a1 * 8000 * 0.5).cpu().numpy()) <= 1e-6      # 2*s+1 itself rounds in fp32
     m = K.rise_apply(g8[:64], sh[:64], cell, torch.ones(1, 224, 224, device=DEV), want_masked=False, want_masks=True)
     assert float(m.min()) >= 0.0 and float(m.max()) <= 1.0
+
+
+# ------------------------------------------------------------------------------ ABI conventions: streams and graphs
+def test_kernels_run_on_the_callers_stream_and_are_graph_capturable(K):
+    """include/xai_hip.h promises: launches go to the stream handed in, never synchronise or allocate,
+    so they can be captured into a hipGraph and replayed."""
+    rng = np.random.default_rng(40)
+    g1 = dev(rng.standard_normal((2, 10, 3, 32, 32)).astype(np.float32))
+    x = dev(rng.standard_normal((2, 3, 32, 32)).astype(np.float32))
+    sal = dev(rng.standard_normal((1, 1024)).astype(np.float32))
+    start, finish = x[0].contiguous(), x[1].contiguous()
+    eager = K.ig_accum(g1, x, 0.0)
+    order_e, rank_e = K.rank(sal)
+    flip_e = K.flip_steps(rank_e[0], True, 32)
+    imgs_e = K.perturb_batch(start, finish, flip_e, 0, 8)
+    # (1) a side stream
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out_s = K.ig_accum(g1, x, 0.0)
+        order_s, _ = K.rank(sal)
+    side.synchronize()
+    np.testing.assert_array_equal(out_s.cpu().numpy(), eager.cpu().numpy())
+    np.testing.assert_array_equal(order_s.cpu().numpy(), order_e.cpu().numpy())
+    # (2) capture + two replays with fresh inputs written into the captured buffers
+    graph = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out_g = K.ig_accum(g1, x, 0.0)
+            order_g, rank_g = K.rank(sal)
+            flip_g = K.flip_steps(rank_g[0], True, 32)
+            imgs_g = K.perturb_batch(start, finish, flip_g, 0, 8)
+    for seed in (41, 42):
+        r = np.random.default_rng(seed)
+        g1.copy_(dev(r.standard_normal((2, 10, 3, 32, 32)).astype(np.float32)))
+        sal.copy_(dev(r.standard_normal((1, 1024)).astype(np.float32)))
+        graph.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out_g.cpu().numpy(), K.ig_accum(g1, x, 0.0).cpu().numpy())
+        np.testing.assert_array_equal(order_g.cpu().numpy()[0], np.argsort(sal.cpu().numpy()[0], kind="stable"))
+        o2, r2 = K.rank(sal)
+        np.testing.assert_array_equal(imgs_g.cpu().numpy(), K.perturb_batch(start, finish, K.flip_steps(r2[0], True, 32), 0, 8).cpu().numpy())
