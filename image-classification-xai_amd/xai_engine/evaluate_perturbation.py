@@ -1,0 +1,71 @@
+"""Command line of the harness counterpart -- the reference's flags
+(XAI_Survey/evaluations/evaluatePerturbation.py:726-750: --image_count --model --attr_func --cuda_num
+--dataset_path) plus what an offline box needs (weights from a local file, class-map path).
+
+    python -m xai_engine.evaluate_perturbation --model R50 --attr_func ig --image_count 1000 \
+        --dataset_path /data/ImageNet/val --class_map /data/correctly_classified_R50.txt --weights r50.pt
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m xai_engine.evaluate_perturbation ...
+
+Pretrained torchvision / timm weights cannot be fetched here; `--weights` takes a state_dict saved with
+torch.save (loaded with weights_only=True); without it the architecture runs with seeded random weights.
+"""
+import argparse
+
+import torch
+
+from . import dist as xd
+from . import harness
+from .sweep import CNN_ATTR_FUNCS
+from .zoo import resnet50, vit_base_patch16_224
+
+MODELS = {
+    # name: (constructor, batch size of the reference's table :627-677, normalisation, num_patches)
+    "R50": (resnet50, 50, (harness.CNN_MEAN, harness.CNN_STD)),
+    "VIT16": (vit_base_patch16_224, 25, (harness.VIT_MEAN, harness.VIT_STD)),
+}
+
+
+def build_parser():
+    p = argparse.ArgumentParser("")
+    p.add_argument("--image_count", type=int, default=1000, help="How many images to test with.")
+    p.add_argument("--model", type=str, default="R50", help="Classifier to use: " + ", ".join(MODELS))
+    p.add_argument("--attr_func", type=str, default="ig", help="attr to use: {" + ", ".join(CNN_ATTR_FUNCS) + "}")
+    p.add_argument("--cuda_num", type=int, default=0, help="GPU to use when not launched by torchrun.")
+    p.add_argument("--dataset_path", type=str, default="../../../ImageNet", help="The path to your dataset input")
+    p.add_argument("--class_map", type=str, default=None, help="correctly_classified_<MODEL>.txt (optional)")
+    p.add_argument("--weights", type=str, default=None, help="state_dict file for the chosen architecture")
+    p.add_argument("--eight_runs", action="store_true", help="drive the eight single_run calls like the reference instead of the fused sweep")
+    p.add_argument("--out_dir", type=str, default="pert_test_results")
+    return p
+
+
+def main(argv=None):
+    args, _ = build_parser().parse_known_args(argv)
+    if args.model not in MODELS:
+        raise SystemExit(f"unknown --model {args.model}; choose from {sorted(MODELS)}")
+    if args.attr_func not in CNN_ATTR_FUNCS:
+        print("Model-attribution mismatch, please use --help.")
+        raise SystemExit(1)
+    rank, world, device = xd.init_from_env()
+    if world == 1:
+        device = torch.device("cuda", args.cuda_num)
+        torch.cuda.set_device(device)
+    ctor, batch_size, norm = MODELS[args.model]
+    model = ctor()
+    if args.weights:
+        model.load_state_dict(torch.load(args.weights, map_location="cpu", weights_only=True))
+    model = model.to(device).eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    testing_dict = {"models": [model, model], "imagenet_dataset": args.dataset_path, "normalize": norm, "img_hw": 224,
+                    "batch_size": batch_size, "attr_func": args.attr_func, "model_name": args.model,
+                    "image_count": args.image_count, "device": str(device), "class_map_path": args.class_map}
+    total, used, _ = harness.evaluate_perturbation(testing_dict, rank=rank, world=world, fused=not args.eight_runs, out_dir=args.out_dir)
+    if rank == 0:
+        print(f"{used} images; means: " + ", ".join(f"{k}={total[k] / max(used, 1):.6f}" for k in total))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
