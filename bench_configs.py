@@ -6,6 +6,7 @@ contract line is bench.py; this script produces the supporting numbers kept unde
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench_configs.py ...
 
   1  Grad-CAM, ResNet-50, one 224x224 image           (latency; parity vs oracle)
+  2  IG / Left-IG through the reference's one-image API (bench.py measures the batched path)
   3  RISE, N masks, ResNet-50, masks sharded over ranks (masks/s; one all-reduce of the partial map)
   4  IG 50 steps on ViT-B/16 (hooked), batch 25 + attention-space IG 20 steps
   5  insertion/deletion sweep, images sharded over ranks (images/s; one 88-byte all-reduce)
@@ -32,7 +33,7 @@ def sync(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="1,3,4,5")
+    ap.add_argument("--configs", default="1,2,3,4,5")
     ap.add_argument("--rise-masks", type=int, default=8000)
     ap.add_argument("--rise-batch", type=int, default=250)
     ap.add_argument("--sweep-images", type=int, default=4, help="images per rank")
@@ -59,7 +60,26 @@ def main():
         a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
         return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
-    resnet = resnet50(seed=0).to(dev) if want & {1, 3, 5} else None
+    resnet = resnet50(seed=0).to(dev) if want & {1, 2, 3, 5} else None
+
+    if 2 in want:
+        xs = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+        with torch.no_grad():
+            ts = resnet(xs.to(dev)).argmax(1)
+        for bs in (50, 25):
+            IG(xs[:1], resnet, 50, bs, 1, 0, dev, ts[0])
+            sync(dev); t0 = time.perf_counter()
+            for i in range(8):
+                IG(xs[i:i + 1], resnet, 50, bs, 1, 0, dev, ts[i])
+            sync(dev); dt = (time.perf_counter() - t0) / 8
+            emit({"config": 2, "workload": f"IG 50 steps ResNet-50, reference API (one image per call, batch_size={bs})",
+                  "ms_per_attribution": dt * 1e3, "attributions_per_s": 1 / dt, "n_gpus": world})
+        sync(dev); t0 = time.perf_counter()
+        for i in range(8):
+            IG(xs[i:i + 1], resnet, 50, 50, .9, 0, dev, ts[i])
+        sync(dev); dt = (time.perf_counter() - t0) / 8
+        emit({"config": 2, "workload": "Left-IG (alpha_star=0.9) 50 steps ResNet-50, reference API, batch_size=50",
+              "ms_per_attribution": dt * 1e3, "attributions_per_s": 1 / dt, "n_gpus": world})
 
     if 1 in want:
         x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(dev)

@@ -1,11 +1,17 @@
 // Integrated-Gradients kernels for gfx950 (MI355X): path interpolation (K1), Left-IG cutoff,
-// Riemann accumulation (K2, the roofline kernel), streaming accumulation, IDGI.
+// Riemann accumulation (K2, the roofline kernel), gradient filing, streaming accumulation, IDGI.
 //
-// All of them are HBM-bound element-wise / strided-reduction work: one lane owns a 16-byte
-// column of the image, every wave-instruction moves 1 KiB contiguously, the step loop keeps
-// 8 independent loads in flight per lane, nothing is staged through LDS because no byte is
-// used twice.  Compiled with -ffp-contract=off: products and sums round separately, exactly
-// like the torch expressions they replace.
+// All of them are HBM-bound element-wise / strided-reduction work with no data reuse, so nothing is
+// staged through LDS; what matters is (see csrc/tune/*.hip for the measurements behind each choice):
+//   * 16-byte lanes, 1 KiB contiguous per wave-instruction;
+//   * K2: a balanced grid (2 workgroups per CU, equal item ranges -- the per-CU load rate saturates
+//     before HBM does), step-outer streaming so the chip walks contiguous [img][step] rows, non-temporal
+//     loads of the once-read gradient stream;
+//   * writes (K1): many short concurrent row streams (2 rows per lane) beat long per-lane streams;
+//   * producers of data that is read much later (gradient filing) use non-temporal stores so that their
+//     dirty lines do not sit in the Infinity Cache when the reader starts.
+// Compiled with -ffp-contract=off: products and sums round separately, exactly like the torch
+// expressions they replace.
 #include "xai_common.h"
 
 namespace {
