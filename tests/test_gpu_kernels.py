@@ -455,3 +455,42 @@ def test_kernels_run_on_the_callers_stream_and_are_graph_capturable(K):
         np.testing.assert_array_equal(order_g.cpu().numpy()[0], np.argsort(sal.cpu().numpy()[0], kind="stable"))
         o2, r2 = K.rank(sal)
         np.testing.assert_array_equal(imgs_g.cpu().numpy(), K.perturb_batch(start, finish, K.flip_steps(r2[0], True, 32), 0, 8).cpu().numpy())
+
+
+# ------------------------------------------------------------------------------ degenerate and ragged shapes
+def test_edge_shapes(K):
+    from oracle import ig as oig, perturb as op, rise as orise
+    from xai_engine import load_library
+    lib = load_library()
+    rng = np.random.default_rng(50)
+    # one step, one image, one pixel
+    g = rng.standard_normal((1, 1, 1, 1, 1)).astype(np.float32); x = rng.standard_normal((1, 1, 1, 1)).astype(np.float32)
+    np.testing.assert_array_equal(K.ig_accum(dev(g), dev(x), 0.0).cpu().numpy(), g[:, 0] * x)
+    np.testing.assert_array_equal(K.ig_interp(dev(x), 0.5, dev(np.array([0.25], np.float32))).cpu().numpy()[0, 0],
+                                  oig.interpolate(x[0], np.full_like(x[0], 0.5), np.array([0.25], np.float32))[0])
+    # a batch that is not a multiple of anything: 7 steps x 3 x 5 x 7 image, ragged last perturbation step
+    start = rng.standard_normal((3, 5, 7)).astype(np.float32); finish = -start
+    sal = rng.standard_normal(35).astype(np.float32)
+    _, rk = K.rank(dev(sal[None]))
+    flip = K.flip_steps(rk[0], False, 4)                                  # 9 steps, last one has 3 pixels
+    plan = op.Plan(35, 4, 50, None)
+    groups, _ = op.flip_groups(sal, 35, plan, None, descending=False)
+    want = np.stack(list(op.sequence(start[None], finish[None], groups)))
+    np.testing.assert_array_equal(K.perturb_batch(dev(start), dev(finish), flip, 0, 9).cpu().numpy(), want)
+    np.testing.assert_array_equal(K.perturb_batch(dev(start), dev(finish), flip, 8, 1).cpu().numpy(), want[8:9])
+    seg, total = K.segment_sums(dev(sal), K.rank(dev(sal[None]))[0][0], False, 4, 9)
+    assert abs(float(seg.sum()) - float(sal.sum())) <= 1e-5 * np.abs(sal).sum()
+    # single mask, single class, single-tap blur
+    grid, shifts, cell = orise.draw_grid_and_shifts((16, 16), 1, 4, 0.5, np.random.RandomState(1))
+    m = K.rise_apply(dev(grid.astype(np.uint8)), dev(shifts), cell, dev(np.ones((1, 16, 16), np.float32)), want_masked=False, want_masks=True)
+    assert np.abs(m.cpu().numpy()[0] - orise.masks_from(grid, shifts, (16, 16), cell)[0, 0]).max() <= 1e-6
+    p, e, a = K.softmax_stats(dev(np.array([[3.0]], np.float32)), 0)
+    assert float(p[0]) == 1.0 and float(e[0]) == 0.0 and int(a[0]) == 0
+    xb = rng.standard_normal((1, 1, 3, 3)).astype(np.float32)
+    np.testing.assert_array_equal(K.blur_sep(dev(xb), dev(np.array([2.0], np.float32))).cpu().numpy(), xb * 4.0)
+    # empty / negative extents are argument errors, not launches
+    t = torch.zeros(4, device=DEV)
+    assert lib.xai_perturb_batch_f32(t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 4, 0, 0, t.data_ptr(), None) == -2
+    assert lib.xai_rise_accum_f64(t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 8, 28, 28, 224, 224, 1.0, t.data_ptr(), None) == -2
+    assert lib.xai_softmax_stats_f32(t.data_ptr(), 1, 4, None, 9, t.data_ptr(), None, None, None) == -2
+    assert lib.xai_ig_accum_f32(t.data_ptr(), 1, 4, None, 5, None, None, t.data_ptr(), None, 0.0, 1, 1, t.data_ptr(), None, None) == -2
