@@ -8,7 +8,6 @@ separately (bench.py --fold-bn 1); parity tests always run the classifier as giv
 """
 import copy
 
-import torch
 
 
 def fold_batchnorm(model):

@@ -40,7 +40,6 @@ def logits_fn_of(model):
 def vit_mini_from(npz, device="cpu"):
     """The reference's mini hooked ViT (tests/golden/vit_mini.npz) rebuilt with the build's own
     architecture; parameter names are identical, so the state dict loads as is."""
-    import sys, os
     from xai_engine.zoo import VisionTransformer
     m = VisionTransformer(img=32, patch=8, dim=32, depth=2, heads=4, num_classes=10).eval()
     sd = {k: torch.from_numpy(npz["w_" + k]) for k in m.state_dict()}
