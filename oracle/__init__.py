@@ -11,11 +11,11 @@ Pinning (how we know the oracle equals the reference):
     order, every perturbed image and the return tuples of the five ins/del metric
     classes are checked in `tests/test_oracle_golden.py` against `tests/golden/*.npz`,
     vectors produced by importing the reference itself (`tests/golden/make_golden.py`).
-  * Grad-CAM (captum 0.7.0 `LayerGradCam`, a dependency that is absent from the reference
-    tree and from this image) and the RISE mask generator (`skimage.transform.resize`,
-    absent, version unpinned by the reference's requirements.txt) are restated from
-    their published algorithms: PARITY UNPINNED for those two (see oracle/gradcam.py,
-    oracle/rise.py).
+  * Grad-CAM: the reference calls captum 0.7.0 `LayerGradCam` (absent from the reference tree and from
+    this image), so parity against captum itself is UNPINNED; the identical arithmetic in the
+    reference-owned ViT_CX CAM code is pinned by tests/golden/cam.npz (see oracle/gradcam.py).
+  * RISE mask generator: `skimage.transform.resize` is absent and its version is unpinned by the
+    reference's requirements.txt -> PARITY UNPINNED at that boundary (see oracle/rise.py).
 
 The reference is Python, so the oracle is Python/NumPy; there is no C to compile.
 """

@@ -1,15 +1,16 @@
 """Oracle: Grad-CAM reduce + bilinear upsample (test infrastructure only).
 
-PARITY UNPINNED.  The reference does not implement Grad-CAM: it calls
-captum==0.7.0 `LayerGradCam(model, model.layer4).attribute(x, target,
-relu_attributions=True)` (XAI_Survey/evaluations/evaluatePerturbation.py:147-153;
-requirements.txt:1).  captum is neither vendored in the reference nor installed here, and
-no reference file stores a Grad-CAM output, so this restates captum's published algorithm:
+PARITY: pinned to the reference-owned CAM arithmetic, unpinned against captum itself.  The reference
+does not implement Grad-CAM: it calls captum==0.7.0 `LayerGradCam(model, model.layer4).attribute(x,
+target, relu_attributions=True)` (XAI_Survey/evaluations/evaluatePerturbation.py:147-153;
+requirements.txt:1).  captum is neither vendored in the reference nor installed here, and no reference
+file stores a captum output, so this restates captum's published algorithm:
     w[c]   = mean over (h,w) of d logit_t / d A[c]
     cam    = relu( sum_c w[c] * A[c] )            (keepdim -> (B,1,h,w))
-and is cross-checked only against the reference-owned CAM arithmetic that is in the tree
-(ViT_CX/get_feature_map.py:17-23 channel weights = spatial mean of gradients;
-ViT_CX/base_cam.py:55-61,129 weighted channel sum, negatives clamped).
+The same arithmetic exists in code the reference does own -- ViT_CX/get_feature_map.py:17-23 (channel
+weights = spatial mean of the gradients) and ViT_CX/base_cam.py:55-61,129 (weighted channel sum,
+negatives clamped) -- and tests/golden/cam.npz holds vectors produced by running exactly those two
+methods (tests/golden/make_golden.py: cam_fixture), which `cam_reduce` must reproduce.
 The upsample is torchvision `Resize((H,W), antialias=True)` on a float tensor, i.e.
 `F.interpolate(mode="bilinear", align_corners=False, antialias=True)`; for up-sampling the
 anti-alias filter degenerates to plain bilinear, which is what `bilinear_up` restates.

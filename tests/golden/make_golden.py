@@ -20,6 +20,8 @@ What is pinned (reference file:line in brackets):
                                MonotonicityTest.py:51-213]
   vit_mini.npz                hooked mini-ViT: pixel IG + attention-space IG (Baselines.IG)
                               [VIT_LRP/ViT_ig.py:57-253, VIT_LRP/ViT_explanation_generator.py:139-386]
+  cam.npz                     Grad-CAM arithmetic of the reference-owned CAM code (ViT_CX/get_feature_map.py:17-23,
+                              ViT_CX/base_cam.py:48-64,129); captum's LayerGradCam itself is absent
   sweep_small.npz             the 10-key Counter of run_perturbation, driven exactly like
                               XAI_Survey/evaluations/evaluatePerturbation.py:448-497
 The only stub is an inert `cvxopt` module (used by the reference only under
@@ -340,6 +342,31 @@ def vit_fixture():
     print("vit_mini.npz", {k: v.shape for k, v in out.items() if not k.startswith("w_")})
 
 
+def cam_fixture():
+    """Grad-CAM arithmetic from the reference-OWNED CAM code (captum itself is absent):
+    ViT_CX/get_feature_map.py:17-23 (weights = mean of the gradients over space) and
+    ViT_CX/base_cam.py:48-64,129 (weighted channel sum, negatives clamped).  base_cam.py imports cv2 and
+    ttach at module level; both are inert stubs here -- the two methods called below are NumPy only."""
+    for name in ("cv2", "ttach"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    from util.attribution_methods.ViT_CX.get_feature_map import get_feature_map
+    from util.attribution_methods.ViT_CX.base_cam import BaseCAM
+    rng = np.random.default_rng(90)
+    out = {}
+    for tag, shape in (("a", (2, 16, 7, 7)), ("b", (1, 256, 7, 7)), ("c", (1, 24, 14, 14))):
+        act = rng.standard_normal(shape).astype(np.float32)
+        grad = rng.standard_normal(shape).astype(np.float32)
+        obj = get_feature_map.__new__(get_feature_map)              # no constructor: it wants a hooked model
+        obj.featuremap_and_grads = types.SimpleNamespace(release=lambda: None)   # for BaseCAM.__del__
+        w = obj.get_cam_weights(None, None, None, act, grad)
+        cam = BaseCAM.get_cam_image(obj, None, None, None, act, grad, eigen_smooth=False)
+        clamped = cam.copy()
+        clamped[clamped < 0] = 0                                     # base_cam.py:129
+        out.update({f"{tag}_act": act, f"{tag}_grad": grad, f"{tag}_weights": w, f"{tag}_cam": cam, f"{tag}_cam_relu": clamped})
+    np.savez(os.path.join(HERE, "cam.npz"), **out)
+    print("cam.npz", {k: v.shape for k, v in out.items()})
+
+
 KEYS = ["MAS_ins", "MAS_del", "RISE_ins", "RISE_del", "AIC_ins", "AIC_del", "LERF_res", "MORF_res", "MONO_pos", "MONO_neg"]
 
 
@@ -352,3 +379,4 @@ if __name__ == "__main__":
     perturb_fixture("perturb_224.npz", 224, 224, 320, 50, keep_images=False, blur_k=(31, 31))
     sweep_fixture()
     vit_fixture()
+    cam_fixture()

@@ -159,6 +159,17 @@ def test_gradcam_and_upsample(K, B, C, h, w):
     assert rel_inf(up, want) <= 2e-6
 
 
+def test_gradcam_vs_reference_owned_cam_vectors(K):
+    """tests/golden/cam.npz: produced by the reference's own ViT_CX CAM code (weights = spatial mean of the
+    gradients, weighted channel sum, negatives clamped)."""
+    g = load_golden("cam.npz")
+    for tag in "abc":
+        act, grad = dev(g[f"{tag}_act"]), dev(g[f"{tag}_grad"])
+        scale = np.abs(g[f"{tag}_cam"]).max()
+        assert np.abs(K.gradcam(act, grad, relu=False).cpu().numpy() - g[f"{tag}_cam"]).max() / scale <= TOL
+        assert np.abs(K.gradcam(act, grad, relu=True).cpu().numpy() - g[f"{tag}_cam_relu"]).max() / scale <= TOL
+
+
 # ------------------------------------------------------------------------------ K4 / K5
 @pytest.mark.parametrize("H,W,s,N", [(224, 224, 8, 40), (30, 45, 7, 9), (32, 32, 4, 5)])
 def test_rise_masks_and_accumulate(K, H, W, s, N):

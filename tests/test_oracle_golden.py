@@ -231,3 +231,14 @@ def test_vit_mini_pixel_ig_and_attention_ig():
     model = vit_mini_from(g)
     assert rel_inf(oig.ig(g["x"], model, 50, 25, 1, 0, int(g["target"])), g["ig"]) <= 1e-5
     assert rel_inf(vit_attr.attention_ig(model, g["x"], int(g["target"]), 20), g["attn_ig"]) <= 1e-5
+
+
+def test_gradcam_reduce_matches_reference_owned_cam_code():
+    """cam.npz comes from ViT_CX/get_feature_map.get_cam_weights + ViT_CX/base_cam.get_cam_image."""
+    g = load_golden("cam.npz")
+    for tag in "abc":
+        act, grad = g[f"{tag}_act"], g[f"{tag}_grad"]
+        scale = np.abs(g[f"{tag}_cam"]).max()
+        assert np.abs(ogc.cam_reduce(act, grad, relu=False) - g[f"{tag}_cam"]).max() / scale <= TOL
+        assert np.abs(ogc.cam_reduce(act, grad, relu=True) - g[f"{tag}_cam_relu"]).max() / scale <= TOL
+        assert rel_inf(grad.mean(axis=(2, 3), dtype=np.float32), g[f"{tag}_weights"]) <= TOL
