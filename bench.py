@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", type=int, default=0, help="1 = NHWC classifier weights (slower with MIOpen fp32 on gfx950)")
     ap.add_argument("--fold-bn", type=int, default=0, help="1 = fold eval-mode BatchNorm into the convolutions (opt-in, see xai_engine/prepare.py)")
-    ap.add_argument("--miopen-find", type=int, default=0, help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find)")
+    ap.add_argument("--miopen-find", type=int, default=0, help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find, minutes on a fresh box)")
+    ap.add_argument("--miopen-db", type=int, default=1, help="1 = reuse the shipped MIOpen find-db (image-classification-xai_amd/miopen_db, "
+                    "recorded by one exhaustive find of this workload on an MI355X) so that find mode costs no search time")
     return ap.parse_args()
 
 
@@ -87,11 +89,26 @@ def cpu_baseline():
             "sample": f"{n_attr} attributions (IG {STEPS_IG} steps, batch 50, ResNet-50 fp32, 3x224x224) in {dt:.2f} s"}
 
 
+def use_shipped_find_db(rank):
+    """Point MIOpen at a private copy of the shipped user find-db (one copy per rank: MIOpen locks the files)."""
+    import shutil
+    import tempfile
+    src = os.path.join(ROOT, "image-classification-xai_amd", "miopen_db")
+    if not os.path.isdir(src) or not os.listdir(src):
+        return False
+    dst = os.path.join(tempfile.gettempdir(), f"xai_miopen_db_{os.getuid()}_{rank}")
+    shutil.rmtree(dst, ignore_errors=True)
+    shutil.copytree(src, dst)
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return True
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    tuned = bool(args.miopen_db) and not args.channels_last and not args.fold_bn and use_shipped_find_db(rank)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -104,7 +121,7 @@ def main():
     from xai_engine.ig import ig_batch
     from xai_engine.zoo import resnet50
 
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find) or tuned
     model = resnet50(seed=0).to(dev)
     if args.fold_bn:
         from xai_engine.prepare import fold_batchnorm
@@ -169,7 +186,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "IG 50 steps, ResNet-50 (seeded random weights), 32-image batch of 3x224x224 per GPU, "
                                    "alpha_star=1, baseline=0", "images_per_gpu": B, "ig_steps": STEPS_IG,
-                       "images_per_pass": args.images_per_pass, "classifier_prep": "conv+bn folded" if args.fold_bn else "none", "parallelism": f"image-sharded x{world}, no data-path collective"},
+                       "images_per_pass": args.images_per_pass, "classifier_prep": "conv+bn folded" if args.fold_bn else "none", "miopen": "find mode with shipped find-db" if tuned else ("find" if args.miopen_find else "immediate mode"), "parallelism": f"image-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "xai_ig_accum_f32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": kern_ms, "launches_timed": len(events)},
