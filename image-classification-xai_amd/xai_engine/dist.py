@@ -6,8 +6,12 @@
   RISE masks  -> rise_sharded: contiguous mask ranges, ONE all-reduce(SUM) of the (H,W) fp64
                  partial map (401 KB at 224x224)                      [generate_emap.py:93-100]
 
-Both messages are latency-bound (<= 0.4 MB); with 7 direct xGMI links per GPU RCCL's
-default algorithm is already one hop per peer, so nothing is tuned beyond "one collective".
+  IG steps    -> ig_step_sharded (latency, not throughput): contiguous step ranges of ONE image, an
+                 all-gather of the per-step logits (Left-IG's cutoff needs all of them) and ONE
+                 all-reduce(SUM) of the (C,H,W) partial sum (602 KB)   [saliencyMethods.py:40-70]
+
+All messages are latency-bound (<= 0.6 MB); with 7 direct xGMI links per GPU RCCL's default
+algorithm is already one hop per peer, so nothing is tuned beyond "one collective".
 """
 import os
 
@@ -79,3 +83,40 @@ def rise_sharded(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, sc
     part = rise(model, image, txt_embedding, device, N=N, s=s, p1=p1, score_fn=score_fn, batch_size=batch_size, masks=masks,
                 mask_range=mask_range(N, rank, world), return_partial=True)
     return all_reduce_sum(part).float()
+
+
+def step_range(n_steps, rank, world):
+    """Contiguous, balanced [lo, hi) of path steps for `rank` (same split as mask_range)."""
+    return mask_range(n_steps, rank, world)
+
+
+def ig_step_sharded(input, model, steps, alpha_star, baseline, device, target_class):
+    """IG / Left-IG of ONE image with the path steps split over the ranks: every rank
+    interpolates and back-propagates its contiguous step range, the per-step logits are all-gathered
+    (Left-IG's cutoff is global), each rank sums the gradients of its steps below the cutoff with the
+    streaming kernel, one all-reduce merges the partial sums and xai_ig_finish_f32 applies
+    / n_use * (x - baseline).  Returns (C,H,W) on every rank.  The sum is associated per rank, so the
+    result equals the single-process IG to rounding (<= 1e-6 relative), not bitwise."""
+    from . import kernels as K
+    from .ig import _prep, getGradientsParallel
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    dev, x, base = _prep(input, baseline, device)
+    alphas = torch.linspace(0, 1, steps).to(dev)
+    lo, hi = step_range(steps, rank, world)
+    n_mine = hi - lo
+    logits = torch.zeros(steps, dtype=torch.float32, device=dev)
+    grads = None
+    if n_mine > 0:
+        imgs = K.ig_interp(x, base, alphas[lo:hi])[0].requires_grad_(True)
+        g, s = getGradientsParallel(imgs, model, target_class)
+        grads = g.reshape((n_mine,) + tuple(x.shape[1:])).contiguous()
+        logits[lo:hi] = s.reshape(-1)
+    all_reduce_sum(logits)                                   # disjoint supports: a sum is an all-gather
+    n_use = steps if alpha_star == 1 else int(K.ig_cutoff(logits.reshape(1, steps), alpha_star)[0])
+    acc = torch.zeros_like(x)
+    cnt = max(0, min(hi, n_use) - lo)
+    if cnt > 0:
+        K.ig_accum_add(grads[:cnt], acc[0])
+    all_reduce_sum(acc)
+    return K.ig_finish(acc, n_use, x, base)[0]

@@ -158,11 +158,12 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-def reduce_counters(local_sum, n_local, device=None, group=None):
-    """One all-reduce(SUM) of [10 metric sums, images used] in fp64 (88 bytes) -> global Counter, count."""
+def reduce_counters(local_sum, n_local, device=None, group=None, world=None):
+    """One all-reduce(SUM) of [10 metric sums, images used] in fp64 (88 bytes) -> global Counter, count.
+    `world=1` (a caller that did not shard) skips the collective even inside an initialised job."""
     import torch.distributed as dist
     vec = torch.tensor([float(local_sum.get(k, 0.0)) for k in KEYS] + [float(n_local)], dtype=torch.float64)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if world != 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if dist.get_backend(group) == "nccl":
             vec = vec.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
@@ -192,7 +193,7 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
         for k in KEYS:                                   # plain sums: see DESIGN.md on the reference's Counter `+=`
             total[k] += float(c[k])
         used += 1
-    return (*reduce_counters(total, used, dev), attr_time)
+    return (*reduce_counters(total, used, dev, world=world), attr_time)
 
 
 def write_csv(path, counter_sum, images_used, attr_time, total_time):

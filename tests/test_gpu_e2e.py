@@ -344,3 +344,77 @@ def test_evaluate_perturbation_on_a_directory(tmp_path):
         assert abs(total[k] - want[k]) <= 1e-9, k
     rows = open(tmp_path / "pert_test_results" / "T" / "ig_4_images.csv").read().strip().splitlines()
     assert len(rows) == 12 and rows[0].startswith("MAS_ins,") and rows[-1].startswith("Total Runtime,")
+
+
+# ------------------------------------------------------------------------------ two ranks on one GPU (gloo)
+_TWO_RANK_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2]); sys.path.insert(0, os.path.join(sys.argv[2], "tests"))
+import numpy as np, torch, torch.distributed as dist
+from conftest import load_golden, rel_inf
+from helpers import tiny_from
+from xai_engine import dist as xd, sweep
+from xai_engine.rise import rise, draw_masks
+from xai_engine.ig import IG
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks drive cuda:0; collectives go through the host
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+g = load_golden("sweep_small.npz")
+model = tiny_from(g, dev)
+# (1) images sharded: 2-rank sums == single-process sums
+images = [torch.from_numpy(g["x"][i:i + 1]) for i in range(3)]
+sal = {i: g["saliency"][i] for i in range(3)}
+def attr_fn_for(idx_iter):
+    return lambda x, t: sal[next(idx_iter)]
+total, used, _ = sweep.sweep_images(images, model, dev, attr_fn_for(iter(sweep.shard_indices(3, rank, world))), img_hw=32, rank=rank, world=world)
+one, used1, _ = sweep.sweep_images(images, model, dev, attr_fn_for(iter(range(3))), img_hw=32, rank=0, world=1) if rank == 0 else (None, 3, None)
+assert used == 3
+if rank == 0:
+    for k in sweep.KEYS:
+        assert abs(total[k] - one[k]) <= 1e-9, (k, total[k], one[k])
+# (2) RISE masks sharded: == single-process rise with the same draw
+x = torch.from_numpy(g["x"][0:1])
+score = lambda b: torch.softmax(model(b), 1)[:, 3]
+np.random.seed(100 + rank)                                          # different draws per rank: rank 0's must win
+masks = draw_masks((32, 32), 60, 4, 0.5)
+got = xd.rise_sharded(model, x, None, dev, N=60, s=4, p1=0.5, score_fn=score, batch_size=16, masks=masks)
+np.random.seed(100)
+ref_masks = draw_masks((32, 32), 60, 4, 0.5)
+want = rise(model, x, None, dev, N=60, s=4, p1=0.5, score_fn=score, batch_size=16, masks=ref_masks)
+assert rel_inf(got.cpu().numpy(), want.cpu().numpy()) <= 1e-6
+# (3) IG steps of one image sharded, IG and Left-IG
+gi = load_golden("ig_small.npz")
+m2 = tiny_from(gi, dev)
+xi = torch.from_numpy(gi["x"]); t = torch.tensor(int(gi["target"]))
+for a_star in (1, 0.9):
+    got = xd.ig_step_sharded(xi, m2, 50, a_star, 0, dev, t)
+    want = IG(xi, m2, 50, 25, a_star, 0, dev, t)
+    assert rel_inf(got.cpu().numpy(), want.cpu().numpy()) <= 1e-5, (a_star, rel_inf(got.cpu().numpy(), want.cpu().numpy()))
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
+    """The three sharding modes (images, RISE masks, IG steps) with world_size 2: both ranks use cuda:0 and
+    reduce through gloo, so the real device data path runs on a 1-GPU box (RCCL itself needs 2 GPUs)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT, PKG
+    script = tmp_path / "worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), PKG, ROOT], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=150)[0])
+    finally:
+        for p in procs:                                   # never leave a rank behind on the GPU
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert f"rank {r} ok" in o
