@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--rise-batch", type=int, default=250)
     ap.add_argument("--sweep-images", type=int, default=4, help="images per rank")
     ap.add_argument("--check", type=int, default=1, help="1 = also compare a reduced case with the CPU oracle")
+    ap.add_argument("--miopen-db", type=int, default=1, help="1 = MIOpen find mode on the shipped find-db (see xai_engine/prepare.py)")
+    ap.add_argument("--record-db", default=None, help="directory to record a find-db into (exhaustive find: minutes)")
     args = ap.parse_args()
     want = {int(c) for c in args.configs.split(",")}
 
@@ -45,6 +47,13 @@ def main():
     rank, world, dev = xd.init_from_env()
     import xai_engine
     xai_engine.load_library()
+    if args.record_db:
+        os.makedirs(args.record_db, exist_ok=True)
+        os.environ["MIOPEN_USER_DB_PATH"] = args.record_db
+        torch.backends.cudnn.benchmark = True
+    elif args.miopen_db:
+        from xai_engine.prepare import use_tuned_miopen_db
+        torch.backends.cudnn.benchmark = use_tuned_miopen_db(rank)
     from xai_engine.zoo import resnet50, vit_base_patch16_224
     from xai_engine.ig import IG, ig_batch
     from xai_engine.gradcam import gradcam_saliency

@@ -108,6 +108,58 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel_v4(const uint8_t* __
   }
 }
 
+// s == 8 fast path (the RISE default): the whole 8x8 grid is one 64-bit word, fetched with wave-uniform
+// (scalar) loads and packed with SALU -- no LDS staging, no barrier, so the short-lived workgroups (12 KB
+// written each) start storing immediately.
+__device__ __forceinline__ unsigned long long pack_grid8(const uint8_t* g) {
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(g);     // 64-byte grids are 8-byte aligned
+  unsigned long long bits = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const unsigned long long row = w[r] & 0x0101010101010101ull;                    // byte c -> bit 8c
+    bits |= ((row * 0x0102040810204080ull) >> 56) << (8 * r);                       // gather the 8 bits, byte 0 -> bit 0
+  }
+  return bits;
+}
+
+__device__ __forceinline__ float blend8(unsigned long long bits, const Tap& r, const Tap& c, float lo, float hi) {
+  const float wr0 = 1.f - r.t, wr1 = r.t, wc0 = 1.f - c.t, wc1 = c.t;
+  float v = ((bits >> (r.i0 * 8 + c.i0)) & 1ull) ? wr0 * wc0 : 0.f;
+  v += ((bits >> (r.i0 * 8 + c.i1)) & 1ull) ? wr0 * wc1 : 0.f;
+  v += ((bits >> (r.i1 * 8 + c.i0)) & 1ull) ? wr1 * wc0 : 0.f;
+  v += ((bits >> (r.i1 * 8 + c.i1)) & 1ull) ? wr1 * wc1 : 0.f;
+  return fminf(fmaxf(v, lo), hi);
+}
+
+__global__ __launch_bounds__(kBlock) void rise_apply_kernel_s8(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
+                                                               int cell_h, int cell_w, const float* __restrict__ image, int C, int H,
+                                                               int W, float* __restrict__ masked, float* __restrict__ masks) {
+  const int n = blockIdx.y;
+  const unsigned long long bits = pack_grid8(grid + static_cast<int64_t>(n) * 64);
+  const float hi = bits != 0ull ? 1.f : 0.f;
+  const float lo = bits == ~0ull ? 1.f : 0.f;
+  const int64_t hw = static_cast<int64_t>(H) * W;
+  const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
+  if (p >= hw) return;
+  const int y = static_cast<int>(p / W), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
+  const int up_h = 9 * cell_h, up_w = 9 * cell_w;
+  const int sx = shift[2 * n + 1];
+  const Tap tr = make_tap(y + shift[2 * n], 8, up_h);
+  float4 m;
+  m.x = blend8(bits, tr, make_tap(x + sx, 8, up_w), lo, hi);
+  m.y = blend8(bits, tr, make_tap(x + 1 + sx, 8, up_w), lo, hi);
+  m.z = blend8(bits, tr, make_tap(x + 2 + sx, 8, up_w), lo, hi);
+  m.w = blend8(bits, tr, make_tap(x + 3 + sx, 8, up_w), lo, hi);
+  if (masks) st4(masks + static_cast<int64_t>(n) * hw + p, m);
+  if (masked) {
+    float* o = masked + static_cast<int64_t>(n) * C * hw + p;
+    for (int c = 0; c < C; ++c) {
+      const float4 v = ld4(image + c * hw + p);
+      st4(o + c * hw, make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w));
+    }
+  }
+}
+
 constexpr int kStage = 256;   // masks staged in LDS per round
 
 __global__ __launch_bounds__(kBlock) void rise_accum_kernel(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
@@ -173,7 +225,10 @@ XAI_EXPORT int xai_rise_apply_f32(const uint8_t* grid, const int32_t* shift, int
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t hw = static_cast<int64_t>(H) * W;
   const bool vec = (W % 4 == 0) && xai_aligned16(image) && xai_aligned16(masked_out) && xai_aligned16(masks_out);
-  if (vec) {
+  if (vec && s == 8 && (reinterpret_cast<uintptr_t>(grid) & 7u) == 0) {
+    dim3 g(static_cast<unsigned>(xai_ceil_div(hw, kBlock * 4)), n_masks);
+    hipLaunchKernelGGL(rise_apply_kernel_s8, g, dim3(kBlock), 0, st, grid, shift, cell_h, cell_w, image, C, H, W, masked_out, masks_out);
+  } else if (vec) {
     dim3 g(static_cast<unsigned>(xai_ceil_div(hw, kBlock * 4)), n_masks);
     hipLaunchKernelGGL(rise_apply_kernel_v4, g, dim3(kBlock), s * s, st, grid, shift, s, cell_h, cell_w, image, C, H, W, masked_out, masks_out);
   } else {
