@@ -69,7 +69,8 @@ def test_ig_accum_on_reference_gradients(K):
     np.testing.assert_array_equal(lig2.cpu().numpy(), lig.cpu().numpy())
 
 
-@pytest.mark.parametrize("shape,n_img,steps", [((3, 224, 224), 3, 50), ((3, 30, 45), 2, 7), ((1, 5, 5), 1, 1), ((3, 64, 64), 2, 19)])
+@pytest.mark.parametrize("shape,n_img,steps", [((3, 224, 224), 3, 50), ((3, 30, 45), 2, 7), ((1, 5, 5), 1, 1), ((3, 64, 64), 2, 19),
+                                                ((1, 16, 16), 3, 11), ((4, 8, 8), 2, 5), ((3, 224, 224), 12, 6)])
 def test_ig_accum_vs_oracle(K, shape, n_img, steps):
     from oracle import ig as oig
     rng = np.random.default_rng(2)
@@ -123,6 +124,15 @@ def test_ig_accum_linearity_full_size(K):
     g2 = g1 * 2.0                                                          # exact scaling in fp32
     a2 = K.ig_accum(g2, x, 0.0)
     np.testing.assert_array_equal(a2.cpu().numpy(), (a1 * 2.0).cpu().numpy())
+    del g2, ones
+    # per-image Left-IG cutoffs on the balanced streaming path (lanes whose items straddle two images)
+    n_use = torch.randint(1, steps + 1, (n_img,), generator=torch.Generator().manual_seed(1), dtype=torch.int32).to(DEV)
+    a3, a3_abs = K.ig_accum(g1, x, 0.5, n_use=n_use, want_abs=True)
+    for i in (0, 7, 31):
+        n = int(n_use[i])
+        want = g1[i, :n].double().mean(0) * (x[i].double() - 0.5)
+        assert rel_inf(a3[i].cpu().numpy(), want.cpu().numpy()) <= 2e-6
+        assert rel_inf(a3_abs[i].cpu().numpy(), want.sum(0).abs().cpu().numpy()) <= 1e-5
 
 
 def test_idgi_kernels(K):
