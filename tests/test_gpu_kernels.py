@@ -133,6 +133,13 @@ def test_ig_accum_linearity_full_size(K):
         want = g1[i, :n].double().mean(0) * (x[i].double() - 0.5)
         assert rel_inf(a3[i].cpu().numpy(), want.cpu().numpy()) <= 2e-6
         assert rel_inf(a3_abs[i].cpu().numpy(), want.sum(0).abs().cpu().numpy()) <= 1e-5
+    # weighted (IDG) form on the same path
+    w1 = torch.randn(n_img, steps, device=DEV, generator=gen)
+    w2 = torch.rand(n_img, steps, device=DEV, generator=gen)
+    a4 = K.ig_accum(g1, x, 0.0, w1=w1, w2=w2)
+    for i in (3, 30):
+        want = (g1[i].double() * (w1[i].double() * w2[i].double()).view(-1, 1, 1, 1)).sum(0) / steps * x[i].double()
+        assert rel_inf(a4[i].cpu().numpy(), want.cpu().numpy()) <= 2e-6
 
 
 def test_idgi_kernels(K):
