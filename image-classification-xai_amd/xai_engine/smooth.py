@@ -10,7 +10,7 @@ Observable behaviour kept from the reference:
 import torch
 
 from . import kernels as K
-from .ig import IG, IDG, hip_device
+from .ig import IG, IDG, hip_device, ig_batch
 
 
 def smoothGrad(attribution, input, model, steps, baseline, target_class, device, sigma_spread=.15, samples=25, vis=False):
@@ -23,15 +23,23 @@ def smoothGrad(attribution, input, model, steps, baseline, target_class, device,
     for i in range(samples):
         noise = torch.normal(mean=0, std=stdev, size=input.shape)           # host RNG stream, as in the reference
         noisy[i] = (x + noise.to(dev))[0]
-        if attribution == "IG":
-            a, _, _ = IG(noisy[i].unsqueeze(0), model, steps, int(steps / 2), 1, baseline, dev, target_class)
-        elif attribution == "LIG":
-            a, _, _ = IG(noisy[i].unsqueeze(0), model, steps, int(steps / 2) / 2, .9, baseline, dev, target_class)
-        elif attribution == "IDG":
-            a, _, _ = IDG(noisy[i].unsqueeze(0), model, steps, int(steps / 2) / 2, baseline, dev, target_class)
-        else:
-            a = torch.zeros(tuple(x.shape[2:]), device=dev)                 # unknown name: rows stay zero
-        first[0, i, 0] = a
+    if attribution == "IG" and steps % int(steps / 2) == 0:
+        # all samples through the multi-image engine: same per-sample arithmetic as `samples` IG calls with
+        # batch_size = steps/2 (the classifier sees 2 x steps interpolants per pass instead of steps/2)
+        targets = torch.as_tensor(target_class).reshape(-1)[:1].repeat(samples)
+        base = baseline.to(dev).expand_as(noisy).contiguous() if torch.is_tensor(baseline) else baseline
+        first[0, :, 0] = ig_batch(noisy, model, targets, steps=steps, alpha_star=1, baseline=base, images_per_pass=2)[:, 0]
+    else:
+        for i in range(samples):
+            if attribution == "IG":
+                a, _, _ = IG(noisy[i].unsqueeze(0), model, steps, int(steps / 2), 1, baseline, dev, target_class)
+            elif attribution == "LIG":
+                a, _, _ = IG(noisy[i].unsqueeze(0), model, steps, int(steps / 2) / 2, .9, baseline, dev, target_class)
+            elif attribution == "IDG":
+                a, _, _ = IDG(noisy[i].unsqueeze(0), model, steps, int(steps / 2) / 2, baseline, dev, target_class)
+            else:
+                a = torch.zeros(tuple(x.shape[2:]), device=dev)             # unknown name: rows stay zero
+            first[0, i, 0] = a
     ones = torch.ones((1, 1) + tuple(x.shape[2:]), dtype=torch.float32, device=dev)
     mean0 = K.ig_accum(first, ones, 0.0)[0, 0]                              # mean over samples (x - 0 == 1)
     mean = mean0.unsqueeze(0).expand(C, -1, -1).contiguous()
