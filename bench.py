@@ -96,12 +96,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     from xai_engine.prepare import use_tuned_miopen_db
     tuned = bool(args.miopen_db) and not args.channels_last and not args.fold_bn and use_tuned_miopen_db(rank)
+    # rehearsal knobs (never set by the driver): XAI_DIST_BACKEND=gloo + XAI_FORCE_DEVICE=0 let several ranks share
+    # the one GPU of a test box so that the N>1 control flow (barrier, max-over-ranks, rank-0 print) can be exercised
+    backend = os.environ.get("XAI_DIST_BACKEND", "nccl")
+    dev_index = int(os.environ.get("XAI_FORCE_DEVICE", local))
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     import xai_engine
     xai_engine.load_library()                      # no extension -> no benchmark
@@ -144,7 +147,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
