@@ -14,6 +14,13 @@ import torch
 
 from conftest import ROOT, PKG, load_golden
 
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 HEADER = os.path.join(ROOT, "include", "xai_hip.h")
 
 
@@ -186,7 +193,7 @@ print("rank", rank, "ok")
 def test_two_rank_gloo_sharding_and_reduction(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", OMP_NUM_THREADS="1")
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))

@@ -18,6 +18,13 @@ import torch
 from conftest import load_golden, rel_inf
 from helpers import tiny_from, logits_fn_of
 
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
@@ -404,7 +411,7 @@ def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
     from conftest import ROOT, PKG
     script = tmp_path / "worker.py"
     script.write_text(_TWO_RANK_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script), PKG, ROOT], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = []
