@@ -135,6 +135,8 @@ class MASMetric(_PerturbationMetric):
         if special_version or return_embeddings:
             raise NotImplementedError("special_version (cvxopt QP smoothing) and return_embeddings are outside the accelerated path")
         r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info, want_density=True)
+        if CLIP_test_info is not None:
+            r["entropy"] = np.ones(r["n_steps"] + 1)        # the reference's CLIP branch never fills it (:143-159,:277-281)
         norm = curves.monotone_normalise(r["response"], r["baseline_pred"], r["original_pred"], falling=(self.mode != 'ins'))
         corrected = curves.mas_correct(norm, r["density"], self.mode)
         return r["n_steps"] + 1, corrected, r["entropy"], r["density"], norm

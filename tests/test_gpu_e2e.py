@@ -425,3 +425,47 @@ def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-3000:]
         assert f"rank {r} ok" in o
+
+
+def test_CLIP_test_info_branch():
+    """The CLIP branch of the metrics (MASTestFunctions.py:143-159,277-281; get_CLIP_pred at
+    evaluatePerturbation.py:68-74): similarities = encode_image(x) @ embeddings.T, softmax at T = 0.1."""
+    from util.test_methods import MASTestFunctions as MAS, AICTestFunctions as AIC
+    from oracle import perturb as op
+    g = load_golden("perturb_small.npz")
+
+    class FakeCLIP(torch.nn.Module):
+        def __init__(self, tiny):
+            super().__init__()
+            self.tiny = tiny
+
+        def encode_image(self, x):
+            return torch.nn.functional.normalize(self.tiny(x), dim=-1)
+
+    model = FakeCLIP(tiny_from(g, DEV))
+    emb = torch.nn.functional.normalize(torch.randn(1, 6, 10, generator=torch.Generator().manual_seed(3)), dim=-1).to(DEV)
+
+    def get_CLIP_pred(input_tensor, mdl, all_classes_embedding):
+        sim = mdl.encode_image(input_tensor) @ all_classes_embedding.squeeze().T
+        cls = sim.argmax().item()
+        return cls, torch.nn.functional.softmax(sim / 0.1, dim=-1)[:, cls].item()
+
+    x = torch.from_numpy(g["x"])
+    info = {"input": x.to(DEV), "embeddings": emb, "prediction_function": get_CLIP_pred}
+    sal = g["saliency"]
+    n, corrected, ent, dens, norm = MAS.MASMetric(model, 1024, "del", 32, torch.zeros_like).single_run(
+        x.clone(), sal, DEV, max_batch_size=10, CLIP_test_info=info)
+    assert n == 33 and (ent == 1).all()
+    # by hand: the oracle's image sequence through the same scoring rule
+    plan = op.Plan(1024, 32, 10, None)
+    groups, _ = op.flip_groups(sal, 1024, plan, None, True)
+    imgs = np.stack(list(op.sequence(g["x"], np.zeros_like(g["x"]), groups)))
+    with torch.no_grad():
+        target, orig = get_CLIP_pred(x.to(DEV), model, emb)
+        _, base = get_CLIP_pred(torch.zeros_like(x).to(DEV), model, emb)
+        sims = model.encode_image(torch.from_numpy(imgs).to(DEV)) @ emb.squeeze().T
+        resp = np.concatenate([[orig], torch.softmax(sims / 0.1, -1)[:, target].cpu().numpy()]).astype(np.float64)
+    want = op.monotone(resp, base, orig, falling=True)
+    assert rel_inf(norm, want) <= 1e-5
+    _, aic = AIC.AICMetric(model, 1024, "del", 32, torch.zeros_like).single_run(x.clone(), sal, DEV, max_batch_size=10, CLIP_test_info=info)
+    assert aic.shape == (33,) and aic[0] == 1
