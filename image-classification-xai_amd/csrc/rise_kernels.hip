@@ -211,6 +211,49 @@ __global__ __launch_bounds__(kBlock) void rise_accum_kernel(const uint8_t* __res
   if (live) atomicAdd(acc_out + p, acc * scale);
 }
 
+// s == 8 accumulate: grids staged as one 64-bit word per mask (packed while staging), score and both shifts
+// as one 8-byte record -- two broadcast LDS reads per mask instead of ~10 byte/word reads.
+__global__ __launch_bounds__(kBlock) void rise_accum_kernel_s8(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
+                                                               const float* __restrict__ scores, int n_masks, int per_slice,
+                                                               int cell_h, int cell_w, int H, int W, double scale,
+                                                               double* __restrict__ acc_out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw8[];
+  const int up_h = 9 * cell_h, up_w = 9 * cell_w;
+  unsigned long long* bits = reinterpret_cast<unsigned long long*>(lds_raw8);   // [kStage]
+  float2* meta = reinterpret_cast<float2*>(bits + kStage);                      // [kStage] {score, packed shifts}
+  Tap* rtap = reinterpret_cast<Tap*>(meta + kStage);                            // [up_h]
+  Tap* ctap = rtap + up_h;                                                      // [up_w]
+  for (int i = threadIdx.x; i < up_h; i += kBlock) rtap[i] = make_tap(i, 8, up_h);
+  for (int i = threadIdx.x; i < up_w; i += kBlock) ctap[i] = make_tap(i, 8, up_w);
+  const int64_t hw = static_cast<int64_t>(H) * W;
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool live = p < hw;
+  const int y = live ? static_cast<int>(p / W) : 0, x = live ? static_cast<int>(p - static_cast<int64_t>(y) * W) : 0;
+  const int n_lo = blockIdx.y * per_slice, n_hi = min(n_lo + per_slice, n_masks);
+  double acc = 0.0;
+  for (int base = n_lo; base < n_hi; base += kStage) {
+    const int cnt = min(kStage, n_hi - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += kBlock) {
+      bits[i] = pack_grid8(grid + static_cast<int64_t>(base + i) * 64);
+      meta[i] = make_float2(scores[base + i], __int_as_float((shift[2 * (base + i)] & 0xFFFF) | (shift[2 * (base + i) + 1] << 16)));
+    }
+    __syncthreads();
+    if (live) {
+      for (int m = 0; m < cnt; ++m) {
+        const unsigned long long b = bits[m];
+        const float2 mt = meta[m];
+        const int sh = __float_as_int(mt.y);
+        const Tap tr = rtap[y + (sh & 0xFFFF)];
+        const Tap tc = ctap[x + (sh >> 16)];
+        const float hi = b != 0ull ? 1.f : 0.f, lo = b == ~0ull ? 1.f : 0.f;
+        acc += static_cast<double>(mt.x) * static_cast<double>(blend8(b, tr, tc, lo, hi));
+      }
+    }
+  }
+  if (live) atomicAdd(acc_out + p, acc * scale);
+}
+
 }  // namespace
 
 XAI_EXPORT int xai_rise_apply_f32(const uint8_t* grid, const int32_t* shift, int n_masks, int s, int cell_h, int cell_w,
@@ -253,6 +296,12 @@ XAI_EXPORT int xai_rise_accum_f64(const uint8_t* grid, const int32_t* shift, con
   const int per = static_cast<int>(xai_ceil_div(n_masks, slices));
   slices = static_cast<int>(xai_ceil_div(n_masks, per));
   dim3 g(static_cast<unsigned>(tiles), slices);
+  if (s == 8 && (reinterpret_cast<uintptr_t>(grid) & 7u) == 0 && cell_h < 32768 && cell_w < 32768) {
+    const size_t lds8 = kStage * (sizeof(unsigned long long) + sizeof(float2)) + static_cast<size_t>(up_h + up_w) * sizeof(Tap);
+    hipLaunchKernelGGL(rise_accum_kernel_s8, g, dim3(kBlock), lds8, static_cast<hipStream_t>(stream), grid, shift, scores, n_masks, per,
+                       cell_h, cell_w, H, W, scale, acc);
+    return xai_launch_status();
+  }
   hipLaunchKernelGGL(rise_accum_kernel, g, dim3(kBlock), lds, static_cast<hipStream_t>(stream), grid, shift, scores, n_masks, per, s,
                      cell_h, cell_w, H, W, scale, acc);
   return xai_launch_status();
