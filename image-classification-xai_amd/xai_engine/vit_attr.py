@@ -59,3 +59,95 @@ class Baselines:
         w = mean.clamp(min=0).mean(0)                                                  # (S,)
         side = int(np.sqrt(S - 1))
         return w[1:].reshape(-1, side, side)
+
+
+def compute_rollout_naive(all_layer_matrices, start_layer=0):
+    """Product of the head-averaged attention matrices, no residual (reference :14-24)."""
+    mats = torch.stack(all_layer_matrices)
+    joint = mats[start_layer]
+    for i in range(start_layer + 1, mats.shape[0]):
+        joint = mats[i].bmm(joint)
+    return joint, mats
+
+
+def compute_rollout_attention(all_layer_matrices, start_layer=0):
+    """Attention rollout with the residual modelled as 0.5*A + 0.5*I (reference :26-45)."""
+    n_tok, bsz = all_layer_matrices[0].shape[1], all_layer_matrices[0].shape[0]
+    eye = torch.eye(n_tok, device=all_layer_matrices[0].device).expand(bsz, n_tok, n_tok)
+    aug = torch.stack(all_layer_matrices) + eye.unsqueeze(0)
+    aug = aug / aug.sum(dim=-1, keepdim=True)
+    joint = aug[start_layer]
+    for i in range(start_layer + 1, aug.shape[0]):
+        joint = aug[i].bmm(joint)
+    return joint, aug
+
+
+def _head_means(model):
+    return [(blk.attn.get_attention_map().sum(dim=1) / blk.attn.get_attention_map().shape[1]).detach() for blk in model.blocks]
+
+
+def _grid(v):
+    side = int(np.sqrt(v.shape[-1]))
+    return v.reshape(-1, side, side)
+
+
+def _generate_naive_rollout(self, input, start_layer=0, device=None):
+    """(reference Baselines.generate_naive_rollout :181-194)"""
+    with torch.no_grad():
+        self.model(input if device is None else input.to(device))
+    layers = _head_means(self.model)
+    rollout, mats = compute_rollout_naive(layers, start_layer=start_layer)
+    return _grid(rollout[:, 0, 1:]), mats, torch.stack(layers)
+
+
+def _generate_rollout(self, input, InFlow=False, start_layer=0, device=None):
+    """Attention rollout (reference Baselines.generate_rollout :196-240; the InFlow/RAVE variant needs
+    residual-stream hooks the accelerated path does not model)."""
+    if InFlow:
+        raise NotImplementedError("InFlow/RAVE rollout is outside the accelerated path")
+    with torch.no_grad():
+        self.model(input if device is None else input.to(device))
+    layers = _head_means(self.model)
+    rollout, mats = compute_rollout_attention(layers, start_layer=start_layer)
+    return _grid(rollout[:, 0, 1:]), mats, torch.stack(layers)
+
+
+def _generate_transition_attention_maps(self, input, target_class, start_layer=0, steps=20, with_integral=True,
+                                        first_state=False, device="cuda:0"):
+    """Transition Attention Maps (reference :306-357): Markov-chain states over the blocks times the
+    integrated attention gradient of the last block -- the same K2-shaped accumulation as Baselines.IG.
+    Returns (states, W_state, final, last head-mean CLS attention, last-step attention gradient)."""
+    dev = hip_device(device)
+    x = input.to(dev, torch.float32)
+    x0 = x.detach().requires_grad_(True)
+    out = self.model(x0, register_hook=True)
+    out[0][target_class].sum().backward()
+    blocks = self.model.blocks
+    maps = [blk.attn.get_attention_map().detach() for blk in blocks]
+    grad0 = blocks[-1].attn.get_attn_gradients()
+    b, h, s, _ = maps[-1].shape
+    states = maps[-1].mean(1)[:, 0, :].reshape(b, 1, s)
+    for i in range(start_layer, len(blocks))[::-1]:
+        attn = maps[i].mean(1)
+        states = torch.einsum('biw, bwh->h', states, attn).reshape(b, 1, s) + states
+    alphas = torch.from_numpy(np.linspace(0, 1, steps)).to(dev, torch.float32)
+    scaled = (x * alphas.reshape(steps, 1, 1, 1)).detach().requires_grad_(True)
+    output = self.model(scaled, register_hook=True)
+    output[:, target_class].sum().backward()
+    g = blocks[-1].attn.get_attn_gradients()                                   # (steps, h, s, s)
+    last_map = blocks[-1].attn.get_attention_map()[-1:].detach()
+    if with_integral:
+        cls_rows = g[:, :, 0, :].contiguous().reshape(1, steps, h, s)
+        ones = torch.ones((1, h, s), dtype=torch.float32, device=dev)
+        W_state = K.ig_accum(cls_rows, ones, 0.0)[0].clamp(min=0).mean(0).reshape(b, 1, s)
+    else:
+        W_state = grad0.clamp(min=0).mean(1)[:, 0, :].reshape(b, 1, s)
+    if first_state:
+        states = maps[-1].mean(1)[:, 0, :].reshape(b, 1, s)
+    final = states * W_state
+    return (_grid(states[:, 0, 1:]), _grid(W_state[:, 0, 1:]), _grid(final[:, 0, 1:]), last_map.mean(1)[0, 0, 1:], g[-1:])
+
+
+Baselines.generate_naive_rollout = _generate_naive_rollout
+Baselines.generate_rollout = _generate_rollout
+Baselines.generate_transition_attention_maps = _generate_transition_attention_maps

@@ -338,6 +338,11 @@ def vit_fixture():
     out["attn_ig"] = b.IG(x.clone(), target, steps=20, device="cpu").detach().numpy()
     out["raw_attn"] = b.generate_raw_attn(x.clone(), "cpu").detach().numpy()
     out["attn_grad"] = b.generate_grad(x.clone(), target, "cpu").detach().numpy()
+    out["naive_rollout"] = b.generate_naive_rollout(x.clone())[0].detach().numpy()
+    out["rollout"] = b.generate_rollout(x.clone())[0].detach().numpy()
+    st, w, fin, last_attn, last_grad = b.generate_transition_attention_maps(x.clone(), target, steps=20, device="cpu")
+    out["tam_states"], out["tam_w"], out["tam_final"] = st.detach().numpy(), w.detach().numpy(), fin.detach().numpy()
+    out["tam_last_attn"], out["tam_last_grad"] = last_attn.detach().numpy(), last_grad.detach().numpy()
     np.savez(os.path.join(HERE, "vit_mini.npz"), **out)
     print("vit_mini.npz", {k: v.shape for k, v in out.items() if not k.startswith("w_")})
 

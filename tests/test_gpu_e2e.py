@@ -307,6 +307,13 @@ def test_vit_pixel_ig_and_attention_ig(attr):
     assert rel_inf(a, g["attn_ig"]) <= 1e-4
     assert rel_inf(b.generate_raw_attn(x, DEV).cpu().numpy(), g["raw_attn"]) <= 1e-4
     assert rel_inf(b.generate_grad(x.clone(), t, DEV).cpu().numpy(), g["attn_grad"]) <= 1e-4
+    xd = x.to(DEV)
+    assert rel_inf(b.generate_naive_rollout(xd)[0].cpu().numpy(), g["naive_rollout"]) <= 1e-4
+    assert rel_inf(b.generate_rollout(xd)[0].cpu().numpy(), g["rollout"]) <= 1e-4
+    st, w, fin, last_attn, last_grad = b.generate_transition_attention_maps(x.clone(), t, steps=20, device=DEV)
+    for got, key in ((st, "tam_states"), (w, "tam_w"), (fin, "tam_final"), (last_attn, "tam_last_attn"), (last_grad, "tam_last_grad")):
+        assert got.shape == g[key].shape and rel_inf(got.detach().cpu().numpy(), g[key]) <= 1e-4, key
+    np.testing.assert_array_equal(w.cpu().numpy(), a)                    # T-Attn's integrated weights are Baselines.IG's map
 
 
 def test_evaluate_perturbation_on_a_directory(tmp_path):
