@@ -151,3 +151,72 @@ def _generate_transition_attention_maps(self, input, target_class, start_layer=0
 Baselines.generate_naive_rollout = _generate_naive_rollout
 Baselines.generate_rollout = _generate_rollout
 Baselines.generate_transition_attention_maps = _generate_transition_attention_maps
+
+
+def _attn_attr(self, input, target_class, start_layer=0, device="cuda:0"):
+    """Attention attribution rollout (reference Baselines.attn_attr :389-414)."""
+    dev = hip_device(device)
+    x0 = input.to(dev, torch.float32).detach().requires_grad_(True)
+    out = self.model(x0, register_hook=True)
+    out[0][target_class].sum().backward()
+    blocks = self.model.blocks
+    b, h, s, _ = blocks[-1].attn.get_attention_map().shape
+    states = blocks[-1].attn.get_attention_map().detach().mean(1)[:, 0, :].reshape(b, 1, s)
+    for i in range(start_layer, len(blocks) - 1)[::-1]:
+        states = states.bmm(blocks[i].attn.get_attention_map().detach().mean(1)) + states
+    W_state = blocks[-1].attn.get_attn_gradients().clamp(min=0).mean(1)[:, 0, :].reshape(b, 1, s)
+    return _grid((states * W_state)[:, 0, 1:])
+
+
+def _bidirectional(self, input, target_class, steps=20, start_layer=4, samples=20, noise=0.2, mae=False, dino=False, ssl=False,
+                   InFlow=False, device="cuda"):
+    """Bidirectional transformer attribution (reference Baselines.bidirectional :417-518, InFlow=False):
+    head-importance-weighted attention rollout R, times the integrated attention gradient of the last block.
+    The integral needs every row of the (heads, S, S) gradient, so all `steps` gradients are reduced by
+    xai_ig_accum_f32 as one [steps][heads*S*S] buffer."""
+    if InFlow:
+        raise NotImplementedError("the InFlow variant needs residual-stream hooks outside the accelerated path")
+    dev = hip_device(device)
+    x = input.to(dev, torch.float32)
+    x0 = x.detach().requires_grad_(True)
+    out = self.model(x0, register_hook=True)
+    out[0][target_class].sum().backward()
+    blocks = self.model.blocks
+    b, num_head, num_tokens, _ = blocks[-1].attn.get_attention_map().shape
+    R = torch.eye(num_tokens, num_tokens, device=dev).expand(b, num_tokens, num_tokens)
+    for nb, blk in enumerate(blocks):
+        if nb < start_layer - 1:
+            continue
+        grad = blk.attn.get_attn_gradients()
+        grad = grad.reshape(-1, grad.shape[-2], grad.shape[-1])
+        cam = blk.attn.get_attention_map().detach()
+        cam = cam.reshape(-1, cam.shape[-2], cam.shape[-1])
+        Ih = torch.mean(torch.matmul(cam.transpose(-1, -2), grad).abs(), dim=(-1, -2))
+        Ih = Ih / torch.sum(Ih)
+        cam = torch.matmul(Ih, cam.reshape(num_head, -1)).reshape(num_tokens, num_tokens)
+        R = R + torch.matmul(cam, R)
+    if ssl:
+        if mae:
+            return R[:, 1:, 1:].abs().mean(axis=1)
+        if dino:
+            return R[:, 1:, 1:].abs().mean(axis=1) + R[:, 0, 1:].abs()
+        return R[:, 0, 1:].abs()
+    alphas = torch.from_numpy(np.linspace(0, 1, steps)).to(dev, torch.float32)
+    scaled = (x * alphas.reshape(steps, 1, 1, 1)).detach().requires_grad_(True)
+    output = self.model(scaled, register_hook=True)
+    output[:, target_class].sum().backward()
+    g = blocks[-1].attn.get_attn_gradients().contiguous()                      # (steps, heads, S, S)
+    n = num_head * num_tokens * num_tokens
+    ones = torch.ones((1, 1, n), dtype=torch.float32, device=dev)
+    mean = K.ig_accum(g.reshape(1, steps, 1, n), ones, 0.0).reshape(num_head, num_tokens, num_tokens)
+    W_state = mean.clamp(min=0).mean(0).reshape(b, num_tokens, num_tokens)
+    attr = W_state * R
+    if mae:
+        return attr[:, 1:, 1:].mean(axis=1)
+    if dino:
+        return attr[:, 1:, 1:].mean(axis=1) + attr[:, 0, 1:]
+    return _grid(attr[:, 0, 1:]), _grid(R[:, 0, 1:])
+
+
+Baselines.attn_attr = _attn_attr
+Baselines.bidirectional = _bidirectional

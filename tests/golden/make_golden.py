@@ -343,6 +343,10 @@ def vit_fixture():
     st, w, fin, last_attn, last_grad = b.generate_transition_attention_maps(x.clone(), target, steps=20, device="cpu")
     out["tam_states"], out["tam_w"], out["tam_final"] = st.detach().numpy(), w.detach().numpy(), fin.detach().numpy()
     out["tam_last_attn"], out["tam_last_grad"] = last_attn.detach().numpy(), last_grad.detach().numpy()
+    out["attn_attr"] = b.attn_attr(x.clone(), target, device="cpu").detach().numpy()
+    bi, bi_R = b.bidirectional(x.clone(), target, steps=20, start_layer=1, device="cpu")
+    out["bi_attr"], out["bi_R"] = bi.detach().numpy(), bi_R.detach().numpy()
+    out["bi_mae"] = b.bidirectional(x.clone(), target, steps=20, start_layer=1, mae=True, device="cpu").detach().numpy()
     np.savez(os.path.join(HERE, "vit_mini.npz"), **out)
     print("vit_mini.npz", {k: v.shape for k, v in out.items() if not k.startswith("w_")})
 

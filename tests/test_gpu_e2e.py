@@ -314,6 +314,10 @@ def test_vit_pixel_ig_and_attention_ig(attr):
     for got, key in ((st, "tam_states"), (w, "tam_w"), (fin, "tam_final"), (last_attn, "tam_last_attn"), (last_grad, "tam_last_grad")):
         assert got.shape == g[key].shape and rel_inf(got.detach().cpu().numpy(), g[key]) <= 1e-4, key
     np.testing.assert_array_equal(w.cpu().numpy(), a)                    # T-Attn's integrated weights are Baselines.IG's map
+    assert rel_inf(b.attn_attr(x.clone(), t, device=DEV).cpu().numpy(), g["attn_attr"]) <= 1e-4
+    bi, bi_R = b.bidirectional(x.clone(), t, steps=20, start_layer=1, device=DEV)
+    assert rel_inf(bi.cpu().numpy(), g["bi_attr"]) <= 1e-4 and rel_inf(bi_R.cpu().numpy(), g["bi_R"]) <= 1e-4
+    assert rel_inf(b.bidirectional(x.clone(), t, steps=20, start_layer=1, mae=True, device=DEV).cpu().numpy(), g["bi_mae"]) <= 1e-4
 
 
 def test_evaluate_perturbation_on_a_directory(tmp_path):
