@@ -15,7 +15,7 @@ import torch
 
 from . import dist as xd
 from . import harness
-from .sweep import CNN_ATTR_FUNCS
+from .sweep import CNN_ATTR_FUNCS, VIT_ATTR_FUNCS
 from .zoo import resnet50, vit_base_patch16_224
 
 MODELS = {
@@ -29,7 +29,8 @@ def build_parser():
     p = argparse.ArgumentParser("")
     p.add_argument("--image_count", type=int, default=1000, help="How many images to test with.")
     p.add_argument("--model", type=str, default="R50", help="Classifier to use: " + ", ".join(MODELS))
-    p.add_argument("--attr_func", type=str, default="ig", help="attr to use: {" + ", ".join(CNN_ATTR_FUNCS) + "}")
+    p.add_argument("--attr_func", type=str, default="ig", help="attr to use: R50: {" + ", ".join(CNN_ATTR_FUNCS) + "}, VIT16: {" +
+                   ", ".join(VIT_ATTR_FUNCS) + "}")
     p.add_argument("--cuda_num", type=int, default=0, help="GPU to use when not launched by torchrun.")
     p.add_argument("--dataset_path", type=str, default="../../../ImageNet", help="The path to your dataset input")
     p.add_argument("--class_map", type=str, default=None, help="correctly_classified_<MODEL>.txt (optional)")
@@ -43,7 +44,7 @@ def main(argv=None):
     args, _ = build_parser().parse_known_args(argv)
     if args.model not in MODELS:
         raise SystemExit(f"unknown --model {args.model}; choose from {sorted(MODELS)}")
-    if args.attr_func not in CNN_ATTR_FUNCS:
+    if args.attr_func not in (VIT_ATTR_FUNCS if "VIT" in args.model else CNN_ATTR_FUNCS):
         print("Model-attribution mismatch, please use --help.")
         raise SystemExit(1)
     rank, world, device = xd.init_from_env()

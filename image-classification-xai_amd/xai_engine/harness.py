@@ -117,8 +117,10 @@ def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pe
     model = testing_dict["models"][0]
     dev = hip_device(testing_dict["device"])
 
+    is_vit = "VIT" in testing_dict["model_name"]                # the reference picks the dispatch table by model name (:577-582)
+
     def attr_fn(x, target):
-        return _sweep.get_CNN_attr(x, None, target, testing_dict)
+        return (_sweep.get_VIT_attr if is_vit else _sweep.get_CNN_attr)(x, None, target, testing_dict)
 
     total, used, attr_time = _sweep.sweep_images([c[1] for c in chosen], model, dev, attr_fn, img_hw=testing_dict["img_hw"],
                                                  batch_size=testing_dict["batch_size"], fused=fused, rank=rank, world=world,

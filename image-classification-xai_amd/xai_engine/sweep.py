@@ -28,6 +28,7 @@ from .smooth import smoothGrad
 
 KEYS = ("MAS_ins", "MAS_del", "RISE_ins", "RISE_del", "AIC_ins", "AIC_del", "LERF_res", "MORF_res", "MONO_pos", "MONO_neg")
 CNN_ATTR_FUNCS = ("grad", "inp_x_grad", "ig", "lig", "idg", "sg", "gc")
+VIT_ATTR_FUNCS = ("attn", "grad", "n_rollout", "rollout", "t_attn", "bi_attn", "attn_ig")
 
 
 def get_CNN_attr(input_tensor, trans_img, target_class, testing_dict):
@@ -62,6 +63,40 @@ def get_CNN_attr(input_tensor, trans_img, target_class, testing_dict):
         print("Model-attribution mismatch, please use --help.")
         raise SystemExit
     return np.abs(np.sum(saliency_map.detach().cpu().numpy(), axis=0))
+
+
+def get_VIT_attr(input_tensor, trans_img, target_class, testing_dict):
+    """(H,W) float32 numpy saliency map of a hooked ViT for the attention-space methods on the accelerated
+    path (reference evaluatePerturbation.py:192-370): patch map (1,p,p) -> bilinear up-sample to the image
+    (torchvision Resize(antialias=True) == plain bilinear when up-sampling) -> abs, the last two fused in
+    xai_bilinear_up_f32.  "attn_ig" (Baselines.IG) is commented out in the reference's table (:276-278) and
+    offered here because it is the config-4 method."""
+    from .vit_attr import Baselines
+    model = testing_dict["models"][0]
+    img_hw = testing_dict["img_hw"]
+    device = testing_dict["device"]
+    attr_function = testing_dict["attr_func"]
+    dev = hip_device(device)
+    explainer = Baselines(model)
+    x = input_tensor.to(dev)
+    if attr_function == "attn":
+        sal = explainer.generate_raw_attn(x, dev)
+    elif attr_function == "grad":
+        sal = explainer.generate_grad(x, target_class, dev)
+    elif attr_function == "n_rollout":
+        sal, _, _ = explainer.generate_naive_rollout(x)
+    elif attr_function == "rollout":
+        sal, _, _ = explainer.generate_rollout(x)
+    elif attr_function == "t_attn":
+        _, _, sal, _, _ = explainer.generate_transition_attention_maps(x, target_class, start_layer=0, device=dev)
+    elif attr_function == "bi_attn":
+        sal, _ = explainer.bidirectional(x, target_class, device=dev)
+    elif attr_function == "attn_ig":
+        sal = explainer.IG(x, target_class, device=dev)
+    else:
+        print("Model-attribution mismatch, please use --help.")
+        raise SystemExit
+    return K.bilinear_up(sal.detach().float().contiguous(), img_hw, img_hw, scale=1.0, take_abs=True)[0].cpu().numpy()
 
 
 def run_perturbation(input_tensor, attribution, testing_dict, CLIP_test_info=None, blur=None):

@@ -480,3 +480,23 @@ def test_CLIP_test_info_branch():
     assert rel_inf(norm, want) <= 1e-5
     _, aic = AIC.AICMetric(model, 1024, "del", 32, torch.zeros_like).single_run(x.clone(), sal, DEV, max_batch_size=10, CLIP_test_info=info)
     assert aic.shape == (33,) and aic[0] == 1
+
+
+def test_get_VIT_attr_dispatch():
+    from helpers import vit_mini_from
+    from xai_engine.sweep import get_VIT_attr, VIT_ATTR_FUNCS
+    g = load_golden("vit_mini.npz")
+    model = vit_mini_from(g, DEV)
+    x = torch.from_numpy(g["x"])
+    t = torch.tensor(int(g["target"]))
+    td = {"models": [model, model], "img_hw": 32, "batch_size": 25, "device": DEV, "num_patches": 4}
+    key = {"attn": "raw_attn", "grad": "attn_grad", "n_rollout": "naive_rollout", "rollout": "rollout", "t_attn": "tam_final", "attn_ig": "attn_ig"}
+    for name in VIT_ATTR_FUNCS:
+        got = get_VIT_attr(x.clone(), None, t, dict(td, attr_func=name))
+        assert got.shape == (32, 32) and got.dtype == np.float32 and (got >= 0).all()
+        if name in key:                        # bi_attn's default start_layer=4 exceeds the mini model's depth: shape check only
+            want = torch.nn.functional.interpolate(torch.from_numpy(g[key[name]])[None], size=(32, 32), mode="bilinear",
+                                                   align_corners=False, antialias=True)[0, 0].abs().numpy()
+            assert rel_inf(got, want) <= 1e-4, (name, rel_inf(got, want))
+    with pytest.raises(SystemExit):
+        get_VIT_attr(x, None, t, dict(td, attr_func="nope"))
