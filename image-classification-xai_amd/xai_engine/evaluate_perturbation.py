@@ -37,6 +37,7 @@ def build_parser():
     p.add_argument("--weights", type=str, default=None, help="state_dict file for the chosen architecture")
     p.add_argument("--eight_runs", action="store_true", help="drive the eight single_run calls like the reference instead of the fused sweep")
     p.add_argument("--out_dir", type=str, default="pert_test_results")
+    p.add_argument("--checkpoint", type=str, default=None, help="path prefix for per-rank resume files (the reference loses a crashed run)")
     return p
 
 
@@ -61,7 +62,8 @@ def main(argv=None):
     testing_dict = {"models": [model, model], "imagenet_dataset": args.dataset_path, "normalize": norm, "img_hw": 224,
                     "batch_size": batch_size, "attr_func": args.attr_func, "model_name": args.model,
                     "image_count": args.image_count, "device": str(device), "class_map_path": args.class_map}
-    total, used, _ = harness.evaluate_perturbation(testing_dict, rank=rank, world=world, fused=not args.eight_runs, out_dir=args.out_dir)
+    total, used, _ = harness.evaluate_perturbation(testing_dict, rank=rank, world=world, fused=not args.eight_runs, out_dir=args.out_dir,
+                                                     checkpoint=args.checkpoint)
     if rank == 0:
         print(f"{used} images; means: " + ", ".join(f"{k}={total[k] / max(used, 1):.6f}" for k in total))
     if world > 1:

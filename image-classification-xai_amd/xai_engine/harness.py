@@ -103,7 +103,7 @@ def select_images(testing_dict, correctly_classified=None, names=None):
     return chosen
 
 
-def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pert_test_results"):
+def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pert_test_results", checkpoint=None):
     """Selection pre-pass, attribution + ten metrics per selected image (sharded over ranks), CSV on
     rank 0.  `testing_dict` has the reference's keys (:705-718): models, imagenet_dataset, img_hw,
     batch_size, attr_func, model_name, image_count, device (+ optional normalize=(mean, std),
@@ -124,7 +124,7 @@ def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pe
 
     total, used, attr_time = _sweep.sweep_images([c[1] for c in chosen], model, dev, attr_fn, img_hw=testing_dict["img_hw"],
                                                  batch_size=testing_dict["batch_size"], fused=fused, rank=rank, world=world,
-                                                 testing_dict=testing_dict)
+                                                 testing_dict=testing_dict, checkpoint=checkpoint)
     if rank == 0 and used:
         name = f'{testing_dict["attr_func"]}_{testing_dict["image_count"]}_images.csv'
         _sweep.write_csv(os.path.join(out_dir, testing_dict["model_name"], name), total, used, attr_time, time.time() - t_start)

@@ -206,29 +206,74 @@ def reduce_counters(local_sum, n_local, device=None, group=None, world=None):
     return Counter({k: float(vec[i]) for i, k in enumerate(KEYS)}), int(round(float(vec[-1])))
 
 
-def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fused=True, rank=0, world=1, testing_dict=None):
+class SweepState:
+    """Per-rank running sums of a sharded sweep, checkpointed so that a crash does not lose the run (the
+    reference writes its CSV once at the very end, evaluatePerturbation.py:612).  One small JSON file per
+    rank, replaced atomically; it is only valid for the same (n_items, rank, world) split."""
+
+    def __init__(self, n_items, rank, world):
+        self.n_items, self.rank, self.world = n_items, rank, world
+        self.sums = {k: 0.0 for k in KEYS}
+        self.used = 0            # images folded into `sums`
+        self.next_pos = 0        # position in this rank's shard list
+        self.attr_time = 0.0
+
+    @staticmethod
+    def path_for(prefix, rank, world):
+        return f"{prefix}.rank{rank}of{world}.json"
+
+    def save(self, prefix):
+        import json
+        path = self.path_for(prefix, self.rank, self.world)
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(dict(n_items=self.n_items, rank=self.rank, world=self.world, sums=self.sums, used=self.used,
+                           next_pos=self.next_pos, attr_time=self.attr_time), f)
+        os.replace(tmp, path)
+
+    @classmethod
+    def load_or_new(cls, prefix, n_items, rank, world):
+        import json
+        st = cls(n_items, rank, world)
+        path = cls.path_for(prefix, rank, world) if prefix else None
+        if path and os.path.exists(path):
+            d = json.load(open(path))
+            if (d.get("n_items"), d.get("rank"), d.get("world")) == (n_items, rank, world) and set(d.get("sums", {})) == set(KEYS):
+                st.sums = {k: float(d["sums"][k]) for k in KEYS}
+                st.used, st.next_pos, st.attr_time = int(d["used"]), int(d["next_pos"]), float(d["attr_time"])
+        return st
+
+
+def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fused=True, rank=0, world=1, testing_dict=None,
+                 checkpoint=None, checkpoint_every=25):
     """Attribution + ten perturbation numbers for every image this rank owns; returns the
     globally reduced (Counter of sums, images used, seconds in attribution).
     images: sequence of (1,C,H,W) CPU/device tensors (already selected -- the order-dependent
     filters of evaluatePerturbation.py:520-576 must run as a deterministic pre-pass so that the
-    1-GPU and N-GPU runs see the same list).  attr_fn(x, target) -> (H,W) float32 numpy map."""
+    1-GPU and N-GPU runs see the same list).  attr_fn(x, target) -> (H,W) float32 numpy map.
+    `checkpoint`: path prefix; every `checkpoint_every` images the rank's running sums are saved and an
+    interrupted sweep with the same split resumes after the last saved image."""
     dev = hip_device(device)
     sweep = PerturbationSweep(model, img_hw, dev, batch_size=batch_size) if fused else None
     td = testing_dict or {"models": [model], "img_hw": img_hw, "batch_size": batch_size, "device": str(dev)}
     blur = GaussianBlur(31, 31, dev)
-    total, used, attr_time = {k: 0.0 for k in KEYS}, 0, 0.0
-    for i in shard_indices(len(images), rank, world):
-        x = images[i]
+    mine = shard_indices(len(images), rank, world)
+    st = SweepState.load_or_new(checkpoint, len(images), rank, world)
+    for pos in range(st.next_pos, len(mine)):
+        x = images[mine[pos]]
         with torch.no_grad():
             target = _logits_of(model(x.to(dev))).argmax(1)[0]
         t0 = time.time()
         sal = attr_fn(x, target)
-        attr_time += time.time() - t0
+        st.attr_time += time.time() - t0
         c = sweep.run(x, sal) if fused else run_perturbation(x.cpu(), sal, td, blur=blur)
         for k in KEYS:                                   # plain sums: see DESIGN.md on the reference's Counter `+=`
-            total[k] += float(c[k])
-        used += 1
-    return (*reduce_counters(total, used, dev, world=world), attr_time)
+            st.sums[k] += float(c[k])
+        st.used += 1
+        st.next_pos = pos + 1
+        if checkpoint and (st.next_pos % checkpoint_every == 0 or st.next_pos == len(mine)):
+            st.save(checkpoint)
+    return (*reduce_counters(st.sums, st.used, dev, world=world), st.attr_time)
 
 
 def write_csv(path, counter_sum, images_used, attr_time, total_time):

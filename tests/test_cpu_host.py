@@ -221,3 +221,17 @@ def test_harness_image_loading_and_name_parsing(tmp_path):
     assert harness.load_image(str(tmp_path / "g.png"), 224).shape == (1, 224, 224)
     n = harness.normalize(t, harness.CNN_MEAN, harness.CNN_STD)
     assert abs(float(n[0, 0, 0]) - (float(t[0, 0, 0]) - 0.485) / 0.229) < 1e-6
+
+
+def test_sweep_state_checkpoint_roundtrip(tmp_path):
+    from xai_engine.sweep import SweepState, KEYS
+    prefix = str(tmp_path / "ckpt")
+    st = SweepState(10, 1, 4)
+    st.sums["MAS_ins"], st.sums["MONO_neg"], st.used, st.next_pos, st.attr_time = 1.25, -0.5, 2, 2, 3.5
+    st.save(prefix)
+    again = SweepState.load_or_new(prefix, 10, 1, 4)
+    assert again.sums == st.sums and (again.used, again.next_pos, again.attr_time) == (2, 2, 3.5)
+    assert set(again.sums) == set(KEYS)
+    fresh = SweepState.load_or_new(prefix, 10, 1, 8)                 # a different split must not resume
+    assert fresh.used == 0 and fresh.next_pos == 0
+    assert SweepState.load_or_new(None, 10, 0, 1).used == 0

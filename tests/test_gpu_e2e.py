@@ -500,3 +500,29 @@ def test_get_VIT_attr_dispatch():
             assert rel_inf(got, want) <= 1e-4, (name, rel_inf(got, want))
     with pytest.raises(SystemExit):
         get_VIT_attr(x, None, t, dict(td, attr_func="nope"))
+
+
+def test_sweep_resumes_from_checkpoint(tmp_path):
+    from xai_engine.sweep import sweep_images, SweepState, KEYS
+    g = load_golden("sweep_small.npz")
+    model = tiny_from(g, DEV)
+    images = [torch.from_numpy(g["x"][i:i + 1]) for i in range(3)]
+    sal = [g["saliency"][i] for i in range(3)]
+    it = iter(range(3))
+    full, used, _ = sweep_images(images, model, DEV, lambda x, t: sal[next(it)], img_hw=32)
+    prefix = str(tmp_path / "ck")
+    calls = []
+
+    def attr_first_two(x, t):
+        calls.append(len(calls))
+        if len(calls) == 3:
+            raise RuntimeError("simulated crash on the third image")
+        return sal[len(calls) - 1]
+    with pytest.raises(RuntimeError):
+        sweep_images(images, model, DEV, attr_first_two, img_hw=32, checkpoint=prefix, checkpoint_every=1)
+    st = SweepState.load_or_new(prefix, 3, 0, 1)
+    assert st.used == 2 and st.next_pos == 2
+    resumed, used2, _ = sweep_images(images, model, DEV, lambda x, t: sal[2], img_hw=32, checkpoint=prefix, checkpoint_every=1)
+    assert used2 == 3
+    for k in KEYS:
+        assert abs(resumed[k] - full[k]) <= 1e-12, k
