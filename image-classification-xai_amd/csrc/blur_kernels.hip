@@ -45,7 +45,42 @@ __global__ __launch_bounds__(kBlock) void blur_sep_kernel(const float* __restric
   }
 }
 
+// One 1-D zero-padded pass along W (axis 1) or H (axis 0) for kernels too long for the fused tile version
+// (the growing-kernel search of the reference's MDA branch goes up to 101 taps): lane = output pixel, taps
+// through the scalar cache, rows of neighbouring lanes coalesce.
+__global__ __launch_bounds__(kBlock) void blur_1d_kernel(const float* __restrict__ x, const float* __restrict__ k1d, int klen, int axis,
+                                                         int H, int W, float* __restrict__ out) {
+  const int64_t plane = static_cast<int64_t>(blockIdx.y) * H * W;
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= static_cast<int64_t>(H) * W) return;
+  const int y = static_cast<int>(p / W), xx = static_cast<int>(p - static_cast<int64_t>(y) * W);
+  const int r = klen / 2;
+  float acc = 0.f;
+  if (axis == 1) {
+    for (int j = 0; j < klen; ++j) {
+      const int gx = xx + j - r;
+      acc += k1d[j] * ((gx >= 0 && gx < W) ? x[plane + static_cast<int64_t>(y) * W + gx] : 0.f);
+    }
+  } else {
+    for (int j = 0; j < klen; ++j) {
+      const int gy = y + j - r;
+      acc += k1d[j] * ((gy >= 0 && gy < H) ? x[plane + static_cast<int64_t>(gy) * W + xx] : 0.f);
+    }
+  }
+  out[plane + p] = acc;
+}
+
 }  // namespace
+
+XAI_EXPORT int xai_blur_1d_f32(const float* x, const float* k1d, int klen, int axis, int B, int C, int H, int W, float* out,
+                               xai_stream_t stream) {
+  XAI_REQUIRE_PTR(x); XAI_REQUIRE_PTR(k1d); XAI_REQUIRE_PTR(out);
+  XAI_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && klen > 0 && (klen & 1) && (axis == 0 || axis == 1) && x != out, XAI_E_SHAPE);
+  XAI_REQUIRE(static_cast<int64_t>(B) * C <= 65535, XAI_E_UNSUPPORTED);
+  dim3 grid(static_cast<unsigned>(xai_ceil_div(static_cast<int64_t>(H) * W, kBlock)), B * C);
+  hipLaunchKernelGGL(blur_1d_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, k1d, klen, axis, H, W, out);
+  return xai_launch_status();
+}
 
 XAI_EXPORT int xai_blur_sep_f32(const float* x, const float* k1d, int klen, int B, int C, int H, int W, float* out,
                                 xai_stream_t stream) {

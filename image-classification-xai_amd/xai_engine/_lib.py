@@ -39,6 +39,7 @@ SIGNATURES = {
     "xai_perturb_batch_f32": [_p, _p, _p, _i, _l, _i, _i, _p, _p],
     "xai_segment_sums_f32": [_p, _p, _l, _i, _i, _i, _p, _p, _p],
     "xai_blur_sep_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
+    "xai_blur_1d_f32": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "xai_softmax_stats_f32": [_p, _i, _i, _p, _i, _p, _p, _p, _p],
 }
 _RESTYPE = {"xai_strerror": C.c_char_p, "xai_rank_workspace_bytes": C.c_size_t, "xai_gradcam_workspace_bytes": C.c_size_t}

@@ -38,3 +38,28 @@ class GaussianBlur:
 
     def __call__(self, x):
         return K.blur_sep(x.to(self.device, torch.float32).contiguous(), self.k1d)
+
+
+def blur_until_unconfident(model, input_tensor, target_class, device, klen=31, ksig=31, threshold_pct=1.0, max_klen=101):
+    """Growing-kernel blur search of the reference's MDA branch (evaluatePerturbation.py:241-257): start at
+    gkern(31,31), add 4 taps / 4 sigma until the blurred image's softmax confidence in `target_class` is at most
+    `threshold_pct` percent or the kernel exceeds `max_klen` taps.  Returns (GaussianBlur, klen, ksig, confidence %)."""
+    dev = hip_device(device)
+    x = input_tensor.to(dev, torch.float32)
+
+    def confidence(b):
+        with torch.no_grad():
+            out = model(b(x))
+            out = out if isinstance(out, torch.Tensor) else out.logits
+            return float(torch.softmax(out, 1)[0, int(target_class)]) * 100
+
+    blur = GaussianBlur(klen, ksig, dev)
+    pct = confidence(blur)
+    while pct > threshold_pct:
+        klen += 4
+        ksig += 4
+        blur = GaussianBlur(klen, ksig, dev)
+        pct = confidence(blur)
+        if klen > max_klen:
+            break
+    return blur, klen, ksig, pct

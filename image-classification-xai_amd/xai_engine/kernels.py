@@ -258,11 +258,18 @@ def segment_sums(sal, order, descending, step_size, n_steps):
 
 
 def blur_sep(x, k1d):
-    """x (B,C,H,W), k1d (klen,) on device -> zero-padded separable blur."""
+    """x (B,C,H,W), k1d (klen,) on device -> zero-padded separable blur.  Up to 63 taps both passes run in
+    one launch (tile + halo in LDS); longer kernels take two 1-D passes through a scratch tensor."""
     _need(x, F32, "x"); _need(k1d, F32, "k1d")
     B, Cc, H, W = x.shape
     out = torch.empty_like(x)
-    _call("xai_blur_sep_f32", x.device, _ptr(x), _ptr(k1d), k1d.numel(), B, Cc, H, W, _ptr(out))
+    klen = k1d.numel()
+    if klen <= 63:
+        _call("xai_blur_sep_f32", x.device, _ptr(x), _ptr(k1d), klen, B, Cc, H, W, _ptr(out))
+    else:
+        tmp = torch.empty_like(x)
+        _call("xai_blur_1d_f32", x.device, _ptr(x), _ptr(k1d), klen, 1, B, Cc, H, W, _ptr(tmp))
+        _call("xai_blur_1d_f32", x.device, _ptr(tmp), _ptr(k1d), klen, 0, B, Cc, H, W, _ptr(out))
     return out
 
 

@@ -166,6 +166,12 @@ int xai_segment_sums_f32(const float* sal, const int32_t* order, int64_t hw, int
 int xai_blur_sep_f32(const float* x, const float* k1d, int klen, int B, int C, int H, int W,
                      float* out, xai_stream_t stream);
 
+/* one zero-padded 1-D pass of the same blur along W (axis = 1) or H (axis = 0), any odd klen; two calls
+ * (through a caller buffer, x != out) give the separable blur for the long kernels of the growing-kernel
+ * search in the MDA branch, evaluatePerturbation.py:244-257 (klen += 4 up to 101) */
+int xai_blur_1d_f32(const float* x, const float* k1d, int klen, int axis, int B, int C, int H,
+                    int W, float* out, xai_stream_t stream);
+
 /* K9  per row of logits: softmax[target], -sum p log2 p, argmax
  * replaces  MASTestFunctions.py:273-276, AICTestFunctions.py:191-192
  *   target_dev : device int32 (NULL -> target_host; target_host < 0 -> each row's argmax)

@@ -522,3 +522,38 @@ def test_edge_shapes(K):
     assert lib.xai_rise_accum_f64(t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 8, 28, 28, 224, 224, 1.0, t.data_ptr(), None) == -2
     assert lib.xai_softmax_stats_f32(t.data_ptr(), 1, 4, None, 9, t.data_ptr(), None, None, None) == -2
     assert lib.xai_ig_accum_f32(t.data_ptr(), 1, 4, None, 5, None, None, t.data_ptr(), None, 0.0, 1, 1, t.data_ptr(), None, None) == -2
+
+
+def test_long_blur_kernels_two_pass(K):
+    """klen > 63 (the MDA growing-kernel search reaches 101 taps): two 1-D passes == dense zero-padded conv2d."""
+    from oracle import perturb as op
+    rng = np.random.default_rng(60)
+    x = rng.standard_normal((1, 3, 40, 52)).astype(np.float32)
+    for klen, sig in ((67, 67), (101, 101)):
+        v = op.gkern1d(klen, sig)
+        got = K.blur_sep(dev(x), dev(v.astype(np.float32))).cpu().numpy()
+        kern = torch.from_numpy(op.gkern(klen, sig))
+        want = torch.nn.functional.conv2d(torch.from_numpy(x), kern, padding=klen // 2).numpy()       # the reference's call
+        assert rel_inf(got, want) <= TOL, (klen, rel_inf(got, want))
+    # both code paths agree at the hand-over length
+    v63 = dev(op.gkern1d(63, 20).astype(np.float32))
+    xd = dev(x)
+    fused = K.blur_sep(xd, v63)
+    tmp = torch.empty_like(fused); out = torch.empty_like(fused)
+    K._call("xai_blur_1d_f32", fused.device, xd.data_ptr(), v63.data_ptr(), 63, 1, 1, 3, 40, 52, tmp.data_ptr())
+    K._call("xai_blur_1d_f32", fused.device, tmp.data_ptr(), v63.data_ptr(), 63, 0, 1, 3, 40, 52, out.data_ptr())
+    np.testing.assert_array_equal(fused.cpu().numpy(), out.cpu().numpy())
+
+
+def test_blur_until_unconfident(K):
+    from xai_engine.blur import blur_until_unconfident, GaussianBlur
+    from helpers import tiny_from
+    g = load_golden("perturb_224.npz")
+    model = tiny_from(g, DEV)
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        t = int(model(x.to(DEV)).argmax(1)[0])
+    blur, klen, ksig, pct = blur_until_unconfident(model, x, t, DEV, threshold_pct=0.0)     # never satisfied -> runs to the cap
+    assert klen == 103 and ksig == 103 and isinstance(blur, GaussianBlur)                   # 31 + 18*4, first value > 101
+    blur2, klen2, _, pct2 = blur_until_unconfident(model, x, t, DEV, threshold_pct=100.0)   # satisfied immediately
+    assert klen2 == 31 and pct2 <= 100.0
