@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes over profiles/bench_kernels.py:
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d F -- python profiles/bench_kernels.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d W -- python profiles/bench_kernels.py
+    python profiles/pmc_kernel_table.py F W > profiles/r01_pmc_kernels.csv
+FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request on wide coalesced reads, MI355X_MICROARCH.md);
+rows are medians over the launches of one (kernel, grid) pair."""
+import collections
+import csv
+import glob
+import re
+import statistics
+import sys
+
+
+def load(d):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if "anonymous namespace" not in n or "at::native" in n:
+            continue
+        n = re.sub(r"^(void )?\(anonymous namespace\)::", "", n)
+        n = re.split(r"\((?=[a-z ]*(float|unsigned|int|long|double))", n)[0]
+        agg[(n, r.get("Grid_Size_X") or r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
+    return agg
+
+
+F, W = load(sys.argv[1]), load(sys.argv[2])
+print("kernel,grid_size,launches,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB,hbm_read_MB_(fetch_x2),hbm_write_MB")
+for k in sorted(F):
+    f = statistics.median(F[k])
+    w = statistics.median(W.get(k, [0]))
+    print(f'"{k[0]}",{k[1]},{len(F[k])},{f:.1f},{w:.1f},{f * 2 * 1024 / 1e6:.2f},{w * 1024 / 1e6:.2f}')
