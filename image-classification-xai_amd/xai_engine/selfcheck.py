@@ -1,0 +1,102 @@
+"""Installation self-check: `python -m xai_engine.selfcheck [--device cuda:0]`.
+
+Runs every kernel of libxai_hip.so once on random data and compares it with the equivalent torch
+expression evaluated ON THE SAME DEVICE (this is a smoke test for a deployment, not the parity suite --
+that lives in tests/ and uses the CPU oracle).  Exit code 0 when everything agrees.
+"""
+import argparse
+import sys
+
+import torch
+import torch.nn.functional as F
+
+from . import kernels as K
+from . import load_library
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    den = b.abs().max().clamp_min(1e-30)
+    return float((a - b).abs().max() / den)
+
+
+def run(device="cuda:0", verbose=True):
+    load_library()
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=gen)      # noqa: E731
+    results = []
+
+    def check(name, err, tol):
+        ok = err <= tol
+        results.append((name, err, tol, ok))
+        if verbose:
+            print(f"{'PASS' if ok else 'FAIL'}  {name:28s} err {err:.2e}  (tol {tol:.0e})")
+
+    x, b = rnd(2, 3, 64, 64), rnd(2, 3, 64, 64) * 0.3
+    al = torch.linspace(0, 1, 20).to(dev)
+    check("ig_interp", _rel(K.ig_interp(x, b, al), b[:, None] + al.view(1, -1, 1, 1, 1) * (x - b)[:, None]), 0.0)
+    g = rnd(2, 20, 3, 64, 64)
+    out, out_abs = K.ig_accum(g, x, b, want_abs=True)
+    ref = g.double().mean(1) * (x - b).double()
+    check("ig_accum", _rel(out, ref), 2e-6)
+    check("ig_accum |sum_c|", _rel(out_abs, ref.sum(1).abs()), 1e-5)
+    lg = rnd(2, 20)
+    nu = K.ig_cutoff(lg, 0.9)
+    want = torch.stack([(row > row.max() * 0.9).nonzero()[0, 0].clamp_min(1) for row in lg]).int()
+    check("ig_cutoff", float((nu - want).abs().max()), 0.0)
+    acc = torch.zeros(1, 3, 64, 64, device=dev)
+    K.ig_accum_add(g[0], acc[0])
+    check("ig_accum_add/finish", _rel(K.ig_finish(acc, 20, x[:1], 0.0), g[0].double().mean(0) * x[0].double()), 2e-6)
+    sq = K.sumsq(g[0])
+    check("sumsq", _rel(sq, (g[0].double() ** 2).flatten(1).sum(1)), 2e-6)
+    act, grad = rnd(2, 96, 7, 7), rnd(2, 96, 7, 7)
+    cam = K.gradcam(act, grad, relu=True)
+    ref = torch.relu((grad.double().mean((2, 3), keepdim=True) * act.double()).sum(1))
+    check("gradcam", float((cam.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)), 1e-5)
+    check("bilinear_up", _rel(K.bilinear_up(cam, 56, 56), F.interpolate(cam[None], size=(56, 56), mode="bilinear", align_corners=False)[0]), 2e-6)
+    sal = rnd(3, 4096).relu()                                        # many ties
+    order, rank = K.rank(sal)
+    check("rank (stable argsort)", float((order.long() - torch.sort(sal, dim=1, stable=True)[1]).abs().max()), 0.0)
+    flip = K.flip_steps(rank[0], True, 64)
+    start, finish = rnd(3, 64, 64), rnd(3, 64, 64)
+    imgs = K.perturb_batch(start, finish, flip, 0, 64)
+    pos = 4095 - rank[0].long()
+    ref = torch.where((pos // 64).view(1, 1, 64, 64) <= torch.arange(64, device=dev).view(-1, 1, 1, 1), finish[None], start[None])
+    check("flip_steps + perturb_batch", _rel(imgs, ref), 0.0)
+    seg, total = K.segment_sums(sal[0], order[0], True, 64, 64)
+    check("segment_sums", _rel(seg, sal[0][order[0].long().flip(0)].view(64, 64).double().sum(1)), 2e-6)
+    z = rnd(9, 1000) * 3
+    p, ent, am = K.softmax_stats(z, 5)
+    sm = torch.softmax(z.double(), 1)
+    check("softmax_stats p", _rel(p, sm[:, 5]), 2e-6)
+    check("softmax_stats entropy", _rel(ent, -(sm * sm.log2()).sum(1)), 1e-5)
+    check("softmax_stats argmax", float((am.long() - z.argmax(1)).abs().max()), 0.0)
+    k1 = torch.softmax(rnd(31), 0)
+    kern = torch.zeros(3, 3, 31, 31, device=dev)
+    for c in range(3):
+        kern[c, c] = torch.outer(k1, k1)
+    xb = rnd(2, 3, 40, 70)
+    check("blur_sep", _rel(K.blur_sep(xb, k1), F.conv2d(xb.double(), kern.double(), padding=15)), 1e-5)
+    grid = (torch.rand(6, 8, 8, device=dev, generator=gen) < 0.5).to(torch.uint8)
+    sh = torch.randint(0, 8, (6, 2), device=dev, generator=gen, dtype=torch.int32)
+    img = rnd(3, 64, 64)
+    masked, masks = K.rise_apply(grid, sh, (8, 8), img, want_masked=True, want_masks=True)
+    check("rise_apply (masked = image*mask)", _rel(masked, img[None] * masks[:, None]), 0.0)
+    check("rise masks in [0,1]", float(max(-masks.min(), masks.max() - 1).clamp_min(0)), 0.0)
+    sc = torch.rand(6, device=dev, generator=gen)
+    check("rise_accum", _rel(K.rise_accum(grid, sh, sc, (8, 8), 64, 64, 0.5), 0.5 * (sc.double().view(-1, 1, 1) * masks.double()).sum(0)), 1e-9)
+    return all(r[3] for r in results), results
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--device", default="cuda:0")
+    args = ap.parse_args(argv)
+    ok, _ = run(args.device)
+    print("all kernels agree with torch on", args.device if ok else "-- FAILURES above")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

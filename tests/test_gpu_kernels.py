@@ -557,3 +557,10 @@ def test_blur_until_unconfident(K):
     assert klen == 103 and ksig == 103 and isinstance(blur, GaussianBlur)                   # 31 + 18*4, first value > 101
     blur2, klen2, _, pct2 = blur_until_unconfident(model, x, t, DEV, threshold_pct=100.0)   # satisfied immediately
     assert klen2 == 31 and pct2 <= 100.0
+
+
+def test_selfcheck_module(K):
+    from xai_engine import selfcheck
+    ok, results = selfcheck.run(DEV, verbose=False)
+    assert ok, [r for r in results if not r[3]]
+    assert len(results) >= 18
