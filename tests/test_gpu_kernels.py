@@ -564,3 +564,37 @@ def test_selfcheck_module(K):
     ok, results = selfcheck.run(DEV, verbose=False)
     assert ok, [r for r in results if not r[3]]
     assert len(results) >= 18
+
+
+def test_reentrant_from_two_host_threads_on_two_streams(K):
+    """include/xai_hip.h: no global mutable state, re-entrant from several host threads on different streams."""
+    import threading
+    rng = np.random.default_rng(70)
+    inputs = []
+    for i in range(2):
+        g = dev(rng.standard_normal((2, 12, 3, 48, 48)).astype(np.float32))
+        x = dev(rng.standard_normal((2, 3, 48, 48)).astype(np.float32))
+        sal = dev(rng.standard_normal((2, 48 * 48)).astype(np.float32))
+        inputs.append((g, x, sal))
+    want = [(K.ig_accum(g, x, 0.0).cpu().numpy(), K.rank(sal)[0].cpu().numpy()) for g, x, sal in inputs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            g, x, sal = inputs[i]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(25):
+                    out = K.ig_accum(g, x, 0.0)
+                    order, _ = K.rank(sal)
+                st.synchronize()
+                np.testing.assert_array_equal(out.cpu().numpy(), want[i][0])
+                np.testing.assert_array_equal(order.cpu().numpy(), want[i][1])
+        except Exception as e:          # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join(timeout=120) for t in threads]
+    assert not errors, errors
