@@ -21,8 +21,9 @@ constexpr int kBlock = 256;
 struct Tap { int i0, i1; float t; };
 
 // value(j) = (1-t)*g[i0] + t*g[i1] for output index j of an n_in -> n_out up-sampling
-__device__ __forceinline__ Tap make_tap(int j, int n_in, int n_out) {
-  double c = (j + 0.5) * (static_cast<double>(n_in) / static_cast<double>(n_out)) - 0.5;
+// `ratio` = double(n_in) / double(n_out), computed once on the host (an fp64 divide per tap made K4 compute-bound)
+__device__ __forceinline__ Tap make_tap(int j, int n_in, double ratio) {
+  double c = (j + 0.5) * ratio - 0.5;
   if (c < 0) c = -c;                                   // mirror about sample 0
   const int i0 = static_cast<int>(floor(c));
   int i1 = i0 + 1;
@@ -43,7 +44,7 @@ __device__ __forceinline__ float blend(const uint8_t* g, int s, const Tap& r, co
 }
 
 __global__ __launch_bounds__(kBlock) void rise_apply_kernel(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift, int s,
-                                                            int cell_h, int cell_w, const float* __restrict__ image, int C, int H,
+                                                            int cell_h, int cell_w, double rh, double rw, const float* __restrict__ image, int C, int H,
                                                             int W, float* __restrict__ masked, float* __restrict__ masks) {
   extern __shared__ uint8_t g[];                        // [s][s]
   const int n = blockIdx.y;
@@ -59,10 +60,9 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel(const uint8_t* __res
   const int64_t hw = static_cast<int64_t>(H) * W;
   const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (p >= hw) return;
-  const int y = static_cast<int>(p / W), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
-  const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
-  const Tap tr = make_tap(y + shift[2 * n], s, up_h);
-  const Tap tc = make_tap(x + shift[2 * n + 1], s, up_w);
+  const int y = static_cast<int>(static_cast<uint32_t>(p) / static_cast<uint32_t>(W)), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
+  const Tap tr = make_tap(y + shift[2 * n], s, rh);
+  const Tap tc = make_tap(x + shift[2 * n + 1], s, rw);
   const float m = blend(g, s, tr, tc, lo, hi);
   if (masks) masks[static_cast<int64_t>(n) * hw + p] = m;
   if (masked) {
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel(const uint8_t* __res
 
 // 4 pixels per lane along x (W % 4 == 0, 16-byte aligned planes)
 __global__ __launch_bounds__(kBlock) void rise_apply_kernel_v4(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
-                                                               int s, int cell_h, int cell_w, const float* __restrict__ image, int C,
-                                                               int H, int W, float* __restrict__ masked, float* __restrict__ masks) {
+                                                               int s, int cell_h, int cell_w, double rh, double rw, const float* __restrict__ image,
+                                                               int C, int H, int W, float* __restrict__ masked, float* __restrict__ masks) {
   extern __shared__ uint8_t g[];
   const int n = blockIdx.y;
   int one = 0, zero = 0;
@@ -89,15 +89,14 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel_v4(const uint8_t* __
   const int64_t hw = static_cast<int64_t>(H) * W;
   const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
   if (p >= hw) return;
-  const int y = static_cast<int>(p / W), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
-  const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
+  const int y = static_cast<int>(static_cast<uint32_t>(p) / static_cast<uint32_t>(W)), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
   const int sx = shift[2 * n + 1];
-  const Tap tr = make_tap(y + shift[2 * n], s, up_h);
+  const Tap tr = make_tap(y + shift[2 * n], s, rh);
   float4 m;
-  m.x = blend(g, s, tr, make_tap(x + sx, s, up_w), lo, hi);
-  m.y = blend(g, s, tr, make_tap(x + 1 + sx, s, up_w), lo, hi);
-  m.z = blend(g, s, tr, make_tap(x + 2 + sx, s, up_w), lo, hi);
-  m.w = blend(g, s, tr, make_tap(x + 3 + sx, s, up_w), lo, hi);
+  m.x = blend(g, s, tr, make_tap(x + sx, s, rw), lo, hi);
+  m.y = blend(g, s, tr, make_tap(x + 1 + sx, s, rw), lo, hi);
+  m.z = blend(g, s, tr, make_tap(x + 2 + sx, s, rw), lo, hi);
+  m.w = blend(g, s, tr, make_tap(x + 3 + sx, s, rw), lo, hi);
   if (masks) st4(masks + static_cast<int64_t>(n) * hw + p, m);
   if (masked) {
     float* o = masked + static_cast<int64_t>(n) * C * hw + p;
@@ -122,18 +121,24 @@ __device__ __forceinline__ unsigned long long pack_grid8(const uint8_t* g) {
   return bits;
 }
 
-__device__ __forceinline__ float blend8(unsigned long long bits, const Tap& r, const Tap& c, float lo, float hi) {
+// the two grid rows a pixel row touches, as bytes (bit c = column c): two 64-bit shifts per lane, the per-pixel
+// tests below are 32-bit
+__device__ __forceinline__ uint2 grid_rows8(unsigned long long bits, const Tap& r) {
+  return make_uint2(static_cast<uint32_t>(bits >> (r.i0 * 8)) & 0xFFu, static_cast<uint32_t>(bits >> (r.i1 * 8)) & 0xFFu);
+}
+
+__device__ __forceinline__ float blend8(uint2 rows, const Tap& r, const Tap& c, float lo, float hi) {
   const float wr0 = 1.f - r.t, wr1 = r.t, wc0 = 1.f - c.t, wc1 = c.t;
-  float v = ((bits >> (r.i0 * 8 + c.i0)) & 1ull) ? wr0 * wc0 : 0.f;
-  v += ((bits >> (r.i0 * 8 + c.i1)) & 1ull) ? wr0 * wc1 : 0.f;
-  v += ((bits >> (r.i1 * 8 + c.i0)) & 1ull) ? wr1 * wc0 : 0.f;
-  v += ((bits >> (r.i1 * 8 + c.i1)) & 1ull) ? wr1 * wc1 : 0.f;
+  float v = ((rows.x >> c.i0) & 1u) ? wr0 * wc0 : 0.f;
+  v += ((rows.x >> c.i1) & 1u) ? wr0 * wc1 : 0.f;
+  v += ((rows.y >> c.i0) & 1u) ? wr1 * wc0 : 0.f;
+  v += ((rows.y >> c.i1) & 1u) ? wr1 * wc1 : 0.f;
   return fminf(fmaxf(v, lo), hi);
 }
 
 __global__ __launch_bounds__(kBlock) void rise_apply_kernel_s8(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
-                                                               int cell_h, int cell_w, const float* __restrict__ image, int C, int H,
-                                                               int W, float* __restrict__ masked, float* __restrict__ masks) {
+                                                               int cell_h, int cell_w, double rh, double rw, const float* __restrict__ image, int C,
+                                                               int H, int W, float* __restrict__ masked, float* __restrict__ masks) {
   const int n = blockIdx.y;
   const unsigned long long bits = pack_grid8(grid + static_cast<int64_t>(n) * 64);
   const float hi = bits != 0ull ? 1.f : 0.f;
@@ -141,15 +146,15 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel_s8(const uint8_t* __
   const int64_t hw = static_cast<int64_t>(H) * W;
   const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
   if (p >= hw) return;
-  const int y = static_cast<int>(p / W), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
-  const int up_h = 9 * cell_h, up_w = 9 * cell_w;
+  const int y = static_cast<int>(static_cast<uint32_t>(p) / static_cast<uint32_t>(W)), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
   const int sx = shift[2 * n + 1];
-  const Tap tr = make_tap(y + shift[2 * n], 8, up_h);
+  const Tap tr = make_tap(y + shift[2 * n], 8, rh);
+  const uint2 rows = grid_rows8(bits, tr);
   float4 m;
-  m.x = blend8(bits, tr, make_tap(x + sx, 8, up_w), lo, hi);
-  m.y = blend8(bits, tr, make_tap(x + 1 + sx, 8, up_w), lo, hi);
-  m.z = blend8(bits, tr, make_tap(x + 2 + sx, 8, up_w), lo, hi);
-  m.w = blend8(bits, tr, make_tap(x + 3 + sx, 8, up_w), lo, hi);
+  m.x = blend8(rows, tr, make_tap(x + sx, 8, rw), lo, hi);
+  m.y = blend8(rows, tr, make_tap(x + 1 + sx, 8, rw), lo, hi);
+  m.z = blend8(rows, tr, make_tap(x + 2 + sx, 8, rw), lo, hi);
+  m.w = blend8(rows, tr, make_tap(x + 3 + sx, 8, rw), lo, hi);
   if (masks) st4(masks + static_cast<int64_t>(n) * hw + p, m);
   if (masked) {
     float* o = masked + static_cast<int64_t>(n) * C * hw + p;
@@ -164,7 +169,7 @@ constexpr int kStage = 256;   // masks staged in LDS per round
 
 __global__ __launch_bounds__(kBlock) void rise_accum_kernel(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
                                                             const float* __restrict__ scores, int n_masks, int per_slice, int s,
-                                                            int cell_h, int cell_w, int H, int W, double scale,
+                                                            int cell_h, int cell_w, double rh, double rw, int H, int W, double scale,
                                                             double* __restrict__ acc_out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
@@ -174,12 +179,12 @@ __global__ __launch_bounds__(kBlock) void rise_accum_kernel(const uint8_t* __res
   int* sh = reinterpret_cast<int*>(sc + kStage);                    // [kStage][2]
   float* lim = reinterpret_cast<float*>(sh + 2 * kStage);           // [kStage][2] clip range of each mask
   uint8_t* gs = reinterpret_cast<uint8_t*>(lim + 2 * kStage);       // [kStage][s*s]
-  for (int i = threadIdx.x; i < up_h; i += kBlock) rtap[i] = make_tap(i, s, up_h);
-  for (int i = threadIdx.x; i < up_w; i += kBlock) ctap[i] = make_tap(i, s, up_w);
+  for (int i = threadIdx.x; i < up_h; i += kBlock) rtap[i] = make_tap(i, s, rh);
+  for (int i = threadIdx.x; i < up_w; i += kBlock) ctap[i] = make_tap(i, s, rw);
   const int64_t hw = static_cast<int64_t>(H) * W;
   const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool live = p < hw;
-  const int y = live ? static_cast<int>(p / W) : 0, x = live ? static_cast<int>(p - static_cast<int64_t>(y) * W) : 0;
+  const int y = live ? static_cast<int>(static_cast<uint32_t>(p) / static_cast<uint32_t>(W)) : 0, x = live ? static_cast<int>(p - static_cast<int64_t>(y) * W) : 0;
   const int n_lo = blockIdx.y * per_slice, n_hi = min(n_lo + per_slice, n_masks);
   const int ss = s * s;
   double acc = 0.0;
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void rise_accum_kernel(const uint8_t* __res
 // as one 8-byte record -- two broadcast LDS reads per mask instead of ~10 byte/word reads.
 __global__ __launch_bounds__(kBlock) void rise_accum_kernel_s8(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
                                                                const float* __restrict__ scores, int n_masks, int per_slice,
-                                                               int cell_h, int cell_w, int H, int W, double scale,
+                                                               int cell_h, int cell_w, double rh, double rw, int H, int W, double scale,
                                                                double* __restrict__ acc_out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw8[];
   const int up_h = 9 * cell_h, up_w = 9 * cell_w;
@@ -223,12 +228,12 @@ __global__ __launch_bounds__(kBlock) void rise_accum_kernel_s8(const uint8_t* __
   float2* meta = reinterpret_cast<float2*>(bits + kStage);                      // [kStage] {score, packed shifts}
   Tap* rtap = reinterpret_cast<Tap*>(meta + kStage);                            // [up_h]
   Tap* ctap = rtap + up_h;                                                      // [up_w]
-  for (int i = threadIdx.x; i < up_h; i += kBlock) rtap[i] = make_tap(i, 8, up_h);
-  for (int i = threadIdx.x; i < up_w; i += kBlock) ctap[i] = make_tap(i, 8, up_w);
+  for (int i = threadIdx.x; i < up_h; i += kBlock) rtap[i] = make_tap(i, 8, rh);
+  for (int i = threadIdx.x; i < up_w; i += kBlock) ctap[i] = make_tap(i, 8, rw);
   const int64_t hw = static_cast<int64_t>(H) * W;
   const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool live = p < hw;
-  const int y = live ? static_cast<int>(p / W) : 0, x = live ? static_cast<int>(p - static_cast<int64_t>(y) * W) : 0;
+  const int y = live ? static_cast<int>(static_cast<uint32_t>(p) / static_cast<uint32_t>(W)) : 0, x = live ? static_cast<int>(p - static_cast<int64_t>(y) * W) : 0;
   const int n_lo = blockIdx.y * per_slice, n_hi = min(n_lo + per_slice, n_masks);
   double acc = 0.0;
   for (int base = n_lo; base < n_hi; base += kStage) {
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void rise_accum_kernel_s8(const uint8_t* __
         const Tap tr = rtap[y + (sh & 0xFFFF)];
         const Tap tc = ctap[x + (sh >> 16)];
         const float hi = b != 0ull ? 1.f : 0.f, lo = b == ~0ull ? 1.f : 0.f;
-        acc += static_cast<double>(mt.x) * static_cast<double>(blend8(b, tr, tc, lo, hi));
+        acc += static_cast<double>(mt.x) * static_cast<double>(blend8(grid_rows8(b, tr), tr, tc, lo, hi));
       }
     }
   }
@@ -267,16 +272,18 @@ XAI_EXPORT int xai_rise_apply_f32(const uint8_t* grid, const int32_t* shift, int
   XAI_REQUIRE(s <= 64 && n_masks <= 65535, XAI_E_UNSUPPORTED);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t hw = static_cast<int64_t>(H) * W;
+  XAI_REQUIRE(hw < (int64_t(1) << 31), XAI_E_UNSUPPORTED);
+  const double rh = static_cast<double>(s) / static_cast<double>((s + 1) * cell_h), rw = static_cast<double>(s) / static_cast<double>((s + 1) * cell_w);
   const bool vec = (W % 4 == 0) && xai_aligned16(image) && xai_aligned16(masked_out) && xai_aligned16(masks_out);
   if (vec && s == 8 && (reinterpret_cast<uintptr_t>(grid) & 7u) == 0) {
     dim3 g(static_cast<unsigned>(xai_ceil_div(hw, kBlock * 4)), n_masks);
-    hipLaunchKernelGGL(rise_apply_kernel_s8, g, dim3(kBlock), 0, st, grid, shift, cell_h, cell_w, image, C, H, W, masked_out, masks_out);
+    hipLaunchKernelGGL(rise_apply_kernel_s8, g, dim3(kBlock), 0, st, grid, shift, cell_h, cell_w, rh, rw, image, C, H, W, masked_out, masks_out);
   } else if (vec) {
     dim3 g(static_cast<unsigned>(xai_ceil_div(hw, kBlock * 4)), n_masks);
-    hipLaunchKernelGGL(rise_apply_kernel_v4, g, dim3(kBlock), s * s, st, grid, shift, s, cell_h, cell_w, image, C, H, W, masked_out, masks_out);
+    hipLaunchKernelGGL(rise_apply_kernel_v4, g, dim3(kBlock), s * s, st, grid, shift, s, cell_h, cell_w, rh, rw, image, C, H, W, masked_out, masks_out);
   } else {
     dim3 g(static_cast<unsigned>(xai_ceil_div(hw, kBlock)), n_masks);
-    hipLaunchKernelGGL(rise_apply_kernel, g, dim3(kBlock), s * s, st, grid, shift, s, cell_h, cell_w, image, C, H, W, masked_out, masks_out);
+    hipLaunchKernelGGL(rise_apply_kernel, g, dim3(kBlock), s * s, st, grid, shift, s, cell_h, cell_w, rh, rw, image, C, H, W, masked_out, masks_out);
   }
   return xai_launch_status();
 }
@@ -287,6 +294,7 @@ XAI_EXPORT int xai_rise_accum_f64(const uint8_t* grid, const int32_t* shift, con
   XAI_REQUIRE(n_masks > 0 && s > 0 && cell_h > 0 && cell_w > 0 && H > 0 && W > 0, XAI_E_SHAPE);
   XAI_REQUIRE(H + cell_h - 1 <= (s + 1) * cell_h && W + cell_w - 1 <= (s + 1) * cell_w, XAI_E_SHAPE);
   const int up_h = (s + 1) * cell_h, up_w = (s + 1) * cell_w;
+  const double rh = static_cast<double>(s) / static_cast<double>(up_h), rw = static_cast<double>(s) / static_cast<double>(up_w);
   const size_t lds = static_cast<size_t>(up_h + up_w) * sizeof(Tap) + kStage * (3 * sizeof(float) + 2 * sizeof(int)) +
                      static_cast<size_t>(kStage) * s * s;
   XAI_REQUIRE(s <= 64 && lds <= 64 * 1024, XAI_E_UNSUPPORTED);
@@ -299,10 +307,10 @@ XAI_EXPORT int xai_rise_accum_f64(const uint8_t* grid, const int32_t* shift, con
   if (s == 8 && (reinterpret_cast<uintptr_t>(grid) & 7u) == 0 && cell_h < 32768 && cell_w < 32768) {
     const size_t lds8 = kStage * (sizeof(unsigned long long) + sizeof(float2)) + static_cast<size_t>(up_h + up_w) * sizeof(Tap);
     hipLaunchKernelGGL(rise_accum_kernel_s8, g, dim3(kBlock), lds8, static_cast<hipStream_t>(stream), grid, shift, scores, n_masks, per,
-                       cell_h, cell_w, H, W, scale, acc);
+                       cell_h, cell_w, rh, rw, H, W, scale, acc);
     return xai_launch_status();
   }
   hipLaunchKernelGGL(rise_accum_kernel, g, dim3(kBlock), lds, static_cast<hipStream_t>(stream), grid, shift, scores, n_masks, per, s,
-                     cell_h, cell_w, H, W, scale, acc);
+                     cell_h, cell_w, rh, rw, H, W, scale, acc);
   return xai_launch_status();
 }
