@@ -526,3 +526,30 @@ def test_sweep_resumes_from_checkpoint(tmp_path):
     assert used2 == 3
     for k in KEYS:
         assert abs(resumed[k] - full[k]) <= 1e-12, k
+
+
+def test_odd_image_size_end_to_end(attr):
+    """75x75 (H*W odd: every kernel takes its scalar path; ragged last perturbation step) through IG and two metrics."""
+    from util.test_methods import MASTestFunctions as MAS, PosNegPertFunctions as PNP
+    from oracle import ig as oig, perturb as op
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    fn = logits_fn_of(model)
+    rng = np.random.default_rng(80)
+    x = rng.standard_normal((1, 3, 75, 75)).astype(np.float32)
+    with torch.no_grad():
+        t = int(model(torch.from_numpy(x).to(DEV)).argmax(1)[0])
+    got = attr.IG(torch.from_numpy(x), model, 20, 10, 1, 0, DEV, torch.tensor(t)).cpu().numpy()
+    assert rel_inf(got, oig.ig(x, model, 20, 10, 1, 0, t)) <= 1e-5
+    lig = attr.IG(torch.from_numpy(x), model, 20, 5, .8, 0.1, DEV, torch.tensor(t)).cpu().numpy()
+    assert rel_inf(lig, oig.ig(x, model, 20, 5, .8, 0.1, t)) <= 1e-5
+    sal = np.abs(got.sum(0)).astype(np.float32)
+    HW, step = 75 * 75, 100                                    # 57 steps, the last one with 25 pixels
+    res = MAS.MASMetric(model, HW, "del", step, torch.zeros_like).single_run(torch.from_numpy(x), sal, DEV, max_batch_size=16)
+    want = op.mas(fn, x, sal, "del", step, np.zeros_like, None, 16)
+    assert res[0] == want[0] == 58
+    for a, b in zip(res[1:], want[1:]):
+        assert rel_inf(a, b) <= 1e-5
+    res = PNP.PositiveNegativePerturbation(model, HW, "lerf", step, torch.zeros_like).single_run(torch.from_numpy(x), sal, DEV, max_batch_size=57)
+    want = op.pnp(fn, x, sal, "lerf", step, np.zeros_like, None, 57)
+    assert rel_inf(res[1], want[1]) <= 1e-5
