@@ -31,7 +31,10 @@ def use_tuned_miopen_db(rank=0, src=None):
     if not os.path.isdir(src) or not os.listdir(src):
         return False
     dst = os.path.join(tempfile.gettempdir(), f"xai_miopen_db_{os.getuid()}_{rank}")
-    shutil.rmtree(dst, ignore_errors=True)
-    shutil.copytree(src, dst)
+    try:
+        shutil.rmtree(dst, ignore_errors=True)
+        shutil.copytree(src, dst)
+    except OSError:
+        return False                 # no writable scratch: stay in immediate mode
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     return True
