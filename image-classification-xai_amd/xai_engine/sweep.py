@@ -141,17 +141,28 @@ class PerturbationSweep:
         with torch.no_grad():
             return _Probe(_logits_of(self.model(images)).detach(), target, out, offset)
 
-    def run(self, input_tensor, attribution, return_curves=False):
+    def launch(self, input_tensor, attribution):
+        """Queue the whole device part of one image (probes, ranking, three sequences) and an asynchronous
+        copy of the curves into pinned host memory; returns a handle for `finish`.  Nothing here waits for the
+        GPU, so the next image can be queued (or the previous one finished) while this one runs.
+        `attribution`: (H,W) float32 NumPy array or device tensor (a device tensor avoids the upload)."""
         dev = self.dev
         n_steps, step, batches = curves.step_plan(self.HW, self.step_size, self.batch_size)
-        img = input_tensor.to(dev, torch.float32).contiguous()
+        if input_tensor.is_cuda:
+            img = input_tensor.to(dev, torch.float32).contiguous()
+        else:
+            img = input_tensor.to(torch.float32).contiguous().pin_memory().to(dev, non_blocking=True)
         blurred = self.blur(img)
         zeros = torch.zeros_like(img)
         orig = self._stats(img, None)
         target = orig.argmax
         pb = self._stats(blurred, target)
         pz = self._stats(zeros, target)
-        sal = torch.as_tensor(np.ascontiguousarray(attribution, dtype=np.float32)).reshape(1, self.HW).to(dev)
+        if torch.is_tensor(attribution) and attribution.is_cuda:
+            sal = attribution.to(dev, torch.float32).reshape(1, self.HW).contiguous()
+        else:
+            host_sal = torch.as_tensor(np.ascontiguousarray(attribution, dtype=np.float32)).reshape(1, self.HW)
+            sal = host_sal.pin_memory().to(dev, non_blocking=True)
         order, rk = K.rank(sal)
         f_desc = K.flip_steps(rk[0], True, step)
         f_asc = K.flip_steps(rk[0], False, step)
@@ -159,9 +170,20 @@ class PerturbationSweep:
         ins = sequence_stats(self._stats, blurred[0], img[0], f_desc, n_steps, batches, target, pb)
         dele = sequence_stats(self._stats, img[0], zeros[0], f_desc, n_steps, batches, target, orig)
         lerf = sequence_stats(self._stats, img[0], zeros[0], f_asc, n_steps, batches, target, orig)
+        packed = torch.cat([ins[0], ins[2].float(), dele[0], dele[2].float(), lerf[0], seg_d, total,
+                            orig.p, pb.p, pz.p, pb.argmax.float(), pz.argmax.float(), target.float()])
+        host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+        host.copy_(packed, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        return (n_steps, host, done, packed)          # `packed` is kept alive until the copy has happened
+
+    def finish(self, handle, return_curves=False):
+        """Wait for `launch`'s copy and do the 225-point curve arithmetic on the host."""
+        n_steps, host_t, done, _ = handle
+        done.synchronize()
+        host = host_t.numpy().astype(np.float64)
         n1 = n_steps + 1
-        host = torch.cat([ins[0], ins[2].float(), dele[0], dele[2].float(), lerf[0], seg_d, total,
-                          orig.p, pb.p, pz.p, pb.argmax.float(), pz.argmax.float(), target.float()]).cpu().numpy().astype(np.float64)
         r_ins, a_ins, r_del, a_del, r_lerf = (host[i * n1:(i + 1) * n1] for i in range(5))
         seg = host[5 * n1:5 * n1 + n_steps].astype(np.float32)
         tot = np.float32(host[5 * n1 + n_steps])
@@ -185,6 +207,9 @@ class PerturbationSweep:
         if return_curves:
             return out, dict(ins=r_ins, dele=r_del, lerf=r_lerf, mas_ins=mas_ins, mas_del=mas_del)
         return out
+
+    def run(self, input_tensor, attribution, return_curves=False):
+        return self.finish(self.launch(input_tensor, attribution), return_curves)
 
 
 # ------------------------------------------------------------------------------ image sweep, sharded over ranks
@@ -259,20 +284,36 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     blur = GaussianBlur(31, 31, dev)
     mine = shard_indices(len(images), rank, world)
     st = SweepState.load_or_new(checkpoint, len(images), rank, world)
-    for pos in range(st.next_pos, len(mine)):
-        x = images[mine[pos]]
-        with torch.no_grad():
-            target = _logits_of(model(x.to(dev))).argmax(1)[0]
-        t0 = time.time()
-        sal = attr_fn(x, target)
-        st.attr_time += time.time() - t0
-        c = sweep.run(x, sal) if fused else run_perturbation(x.cpu(), sal, td, blur=blur)
+
+    def fold(c, pos):
         for k in KEYS:                                   # plain sums: see DESIGN.md on the reference's Counter `+=`
             st.sums[k] += float(c[k])
         st.used += 1
         st.next_pos = pos + 1
         if checkpoint and (st.next_pos % checkpoint_every == 0 or st.next_pos == len(mine)):
             st.save(checkpoint)
+
+    pending = None                                       # (handle, pos) of the image whose device work is in flight
+    try:
+        for pos in range(st.next_pos, len(mine)):
+            x = images[mine[pos]]
+            with torch.no_grad():
+                target = _logits_of(model(x.to(dev))).argmax(1)[0]
+            t0 = time.time()
+            sal = attr_fn(x, target)
+            st.attr_time += time.time() - t0
+            if fused:
+                # one image deep: queue this image's device work, then do the previous image's host arithmetic while it runs
+                handle = sweep.launch(x, sal)
+                if pending is not None:
+                    done, pending = pending, None
+                    fold(sweep.finish(done[0]), done[1])
+                pending = (handle, pos)
+            else:
+                fold(run_perturbation(x.cpu(), sal, td, blur=blur), pos)
+    finally:
+        if pending is not None:                          # also on an exception: the queued image is complete work, keep it
+            fold(sweep.finish(pending[0]), pending[1])
     return (*reduce_counters(st.sums, st.used, dev, world=world), st.attr_time)
 
 
