@@ -10,6 +10,7 @@ contract line is bench.py; this script produces the supporting numbers kept unde
   3  RISE, N masks, ResNet-50, masks sharded over ranks (masks/s; one all-reduce of the partial map)
   4  IG 50 steps on ViT-B/16 (hooked), batch 25 + attention-space IG 20 steps
   5  insertion/deletion sweep, images sharded over ranks (images/s; one 88-byte all-reduce)
+  6  RISE-family maskers on ViT-B/16: ViT-CX and TIS end to end, one image (latency)
 One JSON line per configuration on rank 0.
 """
 import argparse
@@ -193,6 +194,37 @@ def main():
                                        f"image-sharded x{world}", "images": used, "seconds": dt, "images_per_s": used / dt,
               "attr_seconds_rank0": attr_t, "metric_means": {k: total[k] / used for k in KEYS}, "n_gpus": world,
               "collective": "1 all_reduce(SUM) of 11 fp64 = 88 B", **extra})
+
+    if 6 in want:
+        from xai_engine.vit_cx import ViT_CX
+        from xai_engine.tis import TIS
+        vit = vit_base_patch16_224(seed=0).to(dev)
+        x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(6))
+        torch.manual_seed(6); np.random.seed(6)
+        res = {}
+        for name, kw in (("host_noise", {}), ("device_noise", {"device_noise": True})):
+            ViT_CX(vit, x, vit.blocks[-1].norm1, device=str(dev), return_feature_map=False, **kw)
+            sync(dev); t0 = time.perf_counter()
+            for _ in range(3):
+                ViT_CX(vit, x, vit.blocks[-1].norm1, device=str(dev), return_feature_map=False, **kw)
+            sync(dev); res[name] = (time.perf_counter() - t0) / 3 * 1e3
+        from xai_engine import kernels as K
+        from xai_engine.vit_cx import feature_maps, cluster_masks, reshape_function_vit
+        import torch.nn as nn
+        _, fmap = feature_maps(nn.Sequential(vit, nn.Softmax(dim=1)), x.to(dev), vit.blocks[-1].norm1, reshape_function_vit)
+        sync(dev); t0 = time.perf_counter()
+        masks, labels = cluster_masks(K.up_rownorm(fmap, 224, 224), 0.1)
+        sync(dev); t_masks = (time.perf_counter() - t0) * 1e3
+        tis = TIS(vit, batch_size=64)
+        tis(x.to(dev))
+        sync(dev); t0 = time.perf_counter()
+        for _ in range(3):
+            tis(x.to(dev))
+        sync(dev); t_tis = (time.perf_counter() - t0) / 3 * 1e3
+        emit({"config": 6, "workload": "ViT-CX (feature-map maskers) and TIS (1024 token masks) on ViT-B/16, one 3x224x224 image, "
+                                       "seeded random weights", "vit_cx_ms": res["host_noise"], "vit_cx_device_noise_ms": res["device_noise"],
+              "vit_cx_clusters": int(masks.shape[0]), "vit_cx_mask_build_ms_incl_host_clustering": t_masks, "tis_ms": t_tis,
+              "n_gpus": world})
 
     if world > 1:
         import torch.distributed as dist

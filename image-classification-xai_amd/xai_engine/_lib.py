@@ -41,6 +41,10 @@ SIGNATURES = {
     "xai_blur_sep_f32": [_p, _p, _i, _i, _i, _i, _i, _p, _p],
     "xai_blur_1d_f32": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "xai_softmax_stats_f32": [_p, _i, _i, _p, _i, _p, _p, _p, _p],
+    "xai_up_rownorm_f32": [_p, _i, _i, _i, _i, _i, _p, _p],
+    "xai_rownorm_f32": [_p, _i, _l, _p, _p],
+    "xai_cluster_sum_f32": [_p, _p, _p, _i, _l, _p, _p],
+    "xai_causal_apply_f32": [_p, _p, _p, _i, _i, _l, _f, _p, _p],
 }
 _RESTYPE = {"xai_strerror": C.c_char_p, "xai_rank_workspace_bytes": C.c_size_t, "xai_gradcam_workspace_bytes": C.c_size_t}
 

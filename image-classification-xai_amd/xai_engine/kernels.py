@@ -302,3 +302,51 @@ def softmax_stats(logits, target=None, want_entropy=True, want_argmax=True, out=
         p, ent, am = p[offset:offset + B], (None if ent is None else ent[offset:offset + B]), (None if am is None else am[offset:offset + B])
     _call("xai_softmax_stats_f32", logits.device, _ptr(logits), B, K, _ptr(t_dev), t_host, _ptr(p), _ptr(ent), _ptr(am))
     return p, ent, am
+
+
+# ------------------------------------------------------------------------------ feature-map maskers (ViT-CX)
+def up_rownorm(src, H, W):
+    """src (R,h,w) -> (R, H*W): bilinear up-sample (align_corners=False) and per-row min-max normalisation."""
+    _need(src, F32, "src")
+    R, h, w = src.shape
+    out = torch.empty((R, int(H) * int(W)), dtype=F32, device=src.device)
+    _call("xai_up_rownorm_f32", src.device, _ptr(src), R, h, w, int(H), int(W), _ptr(out))
+    return out
+
+
+def rownorm(x, out=None):
+    """x (R,P) -> (x - rowmin) / (rowmax - rowmin); out may alias x."""
+    _need(x, F32, "x")
+    R, P = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _need(out, F32, "out")
+        if out.shape != x.shape:
+            raise ValueError("out must have the shape of x")
+    _call("xai_rownorm_f32", x.device, _ptr(x), R, P, _ptr(out))
+    return out
+
+
+def cluster_sum(rows, members, offs):
+    """rows (R,P); members (R,) int32 row ids grouped by cluster; offs (K+1,) int32 -> (K,P) ordered sums."""
+    _need(rows, F32, "rows"); _need(members, I32, "members"); _need(offs, I32, "offs")
+    R, P = rows.shape
+    K_ = offs.numel() - 1
+    if K_ < 1 or members.numel() > R * max(K_, 1) or members.dim() != 1 or offs.dim() != 1:
+        raise ValueError("members must be 1-D and offs (K+1,) with K >= 1")
+    out = torch.empty((K_, P), dtype=F32, device=rows.device)
+    _call("xai_cluster_sum_f32", rows.device, _ptr(rows), _ptr(members), _ptr(offs), K_, P, _ptr(out))
+    return out
+
+
+def causal_apply(x, masks, noise, noise_scale=0.1):
+    """x (C,H,W); masks (N,H*W); noise (N,C,H,W) standard normal -> (2N,C,H,W): masked+noise rows then image+noise rows."""
+    _need(x, F32, "x"); _need(masks, F32, "masks"); _need(noise, F32, "noise")
+    Cc, H, W = x.shape
+    N = masks.shape[0]
+    if masks.shape != (N, H * W) or noise.shape != (N, Cc, H, W):
+        raise ValueError(f"masks must be ({N},{H * W}) and noise ({N},{Cc},{H},{W})")
+    stack = torch.empty((2 * N, Cc, H, W), dtype=F32, device=x.device)
+    _call("xai_causal_apply_f32", x.device, _ptr(x), _ptr(masks), _ptr(noise), N, Cc, H * W, float(noise_scale), _ptr(stack))
+    return stack

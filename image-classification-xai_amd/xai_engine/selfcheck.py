@@ -86,6 +86,23 @@ def run(device="cuda:0", verbose=True):
     check("rise masks in [0,1]", float(max(-masks.min(), masks.max() - 1).clamp_min(0)), 0.0)
     sc = torch.rand(6, device=dev, generator=gen)
     check("rise_accum", _rel(K.rise_accum(grid, sh, sc, (8, 8), 64, 64, 0.5), 0.5 * (sc.double().view(-1, 1, 1) * masks.double()).sum(0)), 1e-9)
+    fm = rnd(10, 5, 5)
+    up = F.interpolate(fm[None].double(), size=(32, 32), mode="bilinear", align_corners=False)[0].flatten(1)
+    lo, hi = up.min(1, keepdim=True)[0], up.max(1, keepdim=True)[0]
+    rows = K.up_rownorm(fm, 32, 32)
+    check("up_rownorm", float((rows.double() - (up - lo) / (hi - lo)).abs().max()), 2e-6)
+    flat = rnd(7, 1000)
+    lo, hi = flat.min(1, keepdim=True)[0], flat.max(1, keepdim=True)[0]
+    check("rownorm", _rel(K.rownorm(flat), (flat - lo) / (hi - lo)), 0.0)
+    labels = torch.tensor([2, 0, 1, 0, 2, 2, 1, 0, 1, 2])
+    members = torch.argsort(labels, stable=True).int().to(dev)
+    offs = torch.tensor([0, 3, 6, 10], dtype=torch.int32, device=dev)
+    ref = torch.zeros(3, 1024, device=dev, dtype=torch.float64).index_add_(0, labels.to(dev), rows.double())
+    check("cluster_sum", _rel(K.cluster_sum(rows, members, offs), ref), 2e-6)
+    m, noise = torch.rand(4, 64 * 64, device=dev, generator=gen), rnd(4, 3, 64, 64)
+    stack = K.causal_apply(img, m, noise, 0.1)
+    add = (noise * 0.1) * (1 - m.view(4, 1, 64, 64))
+    check("causal_apply", _rel(stack, torch.cat([img[None] * m.view(4, 1, 64, 64) + add, img[None] + add])), 0.0)
     return all(r[3] for r in results), results
 
 

@@ -28,7 +28,7 @@ from .smooth import smoothGrad
 
 KEYS = ("MAS_ins", "MAS_del", "RISE_ins", "RISE_del", "AIC_ins", "AIC_del", "LERF_res", "MORF_res", "MONO_pos", "MONO_neg")
 CNN_ATTR_FUNCS = ("grad", "inp_x_grad", "ig", "lig", "idg", "sg", "gc")
-VIT_ATTR_FUNCS = ("attn", "grad", "n_rollout", "rollout", "t_attn", "bi_attn", "attn_ig")
+VIT_ATTR_FUNCS = ("attn", "grad", "n_rollout", "rollout", "t_attn", "bi_attn", "attn_ig", "VIT_CX", "TIS")
 
 
 def get_CNN_attr(input_tensor, trans_img, target_class, testing_dict):
@@ -93,6 +93,20 @@ def get_VIT_attr(input_tensor, trans_img, target_class, testing_dict):
         sal, _ = explainer.bidirectional(x, target_class, device=dev)
     elif attr_function == "attn_ig":
         sal = explainer.IG(x, target_class, device=dev)
+    elif attr_function == "VIT_CX":
+        # :231-235: ViT-CX map of the top-1 class (the reference does not pass target_class), min-max normalised, times
+        # ones(H,W,3), then |sum over the 3 copies| = 3 * normalised map.  The reference passes gpu_batch=1; the batch only
+        # groups the 2N masked forwards, 50 is ViT_CX's own default.
+        from .vit_cx import ViT_CX
+        result, _ = ViT_CX(model, x, model.blocks[-1].norm1, device=device, gpu_batch=testing_dict.get("vit_cx_batch", 50),
+                           return_feature_map=False)
+        result = result.reshape(img_hw, img_hw)
+        result = (result - result.min()) / (result.max() - result.min())
+        return (result * 3.0).abs().numpy()
+    elif attr_function == "TIS":
+        from .tis import TIS
+        # :236-239 (n_masks is the class default, 1024, in the reference; the key exists for models with fewer channels)
+        sal = TIS(model, n_masks=testing_dict.get("tis_n_masks", 1024), batch_size=64)(x, class_idx=target_class)[None]
     else:
         print("Model-attribution mismatch, please use --help.")
         raise SystemExit

@@ -135,6 +135,7 @@ class Block(nn.Module):
 class PatchEmbed(nn.Module):
     def __init__(self, patch, dim):
         super().__init__()
+        self.patch_size = (patch, patch)
         self.proj = nn.Conv2d(3, dim, patch, stride=patch)
 
     def forward(self, x):
@@ -151,6 +152,7 @@ class VisionTransformer(nn.Module):
         n = (img // patch) ** 2
         self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, dim))
+        self.pos_drop = nn.Identity()        # the reference's Dropout(p=0) (ViT_ig.py:175): TIS hangs its token-sampling hook here
         self.blocks = nn.ModuleList([Block(dim, heads) for _ in range(depth)])
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         self.head = nn.Linear(dim, num_classes)
@@ -165,7 +167,7 @@ class VisionTransformer(nn.Module):
     def forward(self, x, register_hook=False):
         B = x.shape[0]
         x = self.patch_embed(x)
-        x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed
+        x = self.pos_drop(torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed)
         for blk in self.blocks:
             x = blk(x, register_hook)
         return self.head(self.norm(x)[:, 0])

@@ -180,6 +180,33 @@ int xai_softmax_stats_f32(const float* logits, int B, int K, const int32_t* targ
                           int target_host, float* p_target, float* entropy_bits,
                           int32_t* argmax, xai_stream_t stream);
 
+/* ---- feature-map maskers of the RISE family (ViT-CX) ---------------------------------- */
+
+/* K11 masks[r] = minmax_row( bilinear_up(src[r], (H,W), align_corners = False) ), one launch, the up-sampled
+ *     maps never exist un-normalised in memory
+ * replaces  ViT_CX/ViT_CX.py:82-84 (transforms.Resize(input_size, antialias=True), then norm_matrix :29-34)
+ *   src : [R][h*w], h*w <= 4096, h*W <= 8192, H <= 1024;  out : [R][H*W];  a constant row gives 0/0 = NaN as in the reference */
+int xai_up_rownorm_f32(const float* src, int R, int h, int w, int H, int W, float* out,
+                       xai_stream_t stream);
+
+/* K12 out[r] = (x[r] - min x[r]) / (max x[r] - min x[r])      (in place allowed)
+ * replaces  norm_matrix, ViT_CX/ViT_CX.py:29-34, as applied to the cluster sums at :109 */
+int xai_rownorm_f32(const float* x, int R, int64_t P, float* out, xai_stream_t stream);
+
+/* K13 out[k] = sum of rows[members[m]] for m in [offs[k], offs[k+1]), added in that order starting from 0
+ * replaces  the `mask_clustering[cluster_labels[i]] += mask[i]` loop, ViT_CX/ViT_CX.py:105-106
+ *   rows : [R][P];  members : int32 row ids grouped by cluster (ascending inside a cluster);
+ *   offs : [K+1] int32;  out : [K][P] */
+int xai_cluster_sum_f32(const float* rows, const int32_t* members, const int32_t* offs, int K,
+                        int64_t P, float* out, xai_stream_t stream);
+
+/* K14 add = (noise[n][c][p] * noise_scale) * (1 - masks[n][p]);
+ *     stack[n][c][p] = x[c][p] * masks[n][p] + add;   stack[N + n][c][p] = x[c][p] + add
+ * replaces  ViT_CX/causal_score.py:27-47 (masks_inverse, random_whole * 0.1, the per-mask loop, torch.cat)
+ *   x : [C][HW];  masks : [N][HW];  noise : [N][C][HW] standard normal draws;  stack : [2N][C][HW] */
+int xai_causal_apply_f32(const float* x, const float* masks, const float* noise, int N, int C,
+                         int64_t HW, float noise_scale, float* stack, xai_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

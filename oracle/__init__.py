@@ -14,6 +14,9 @@ Pinning (how we know the oracle equals the reference):
   * Grad-CAM: the reference calls captum 0.7.0 `LayerGradCam` (absent from the reference tree and from
     this image), so parity against captum itself is UNPINNED; the identical arithmetic in the
     reference-owned ViT_CX CAM code is pinned by tests/golden/cam.npz (see oracle/gradcam.py).
+  * ViT-CX / TIS: every function of the two reference files that runs without torchvision / fast_pytorch_kmeans is
+    pinned by tests/golden/vit_cx.npz and tis.npz; torchvision's Resize inside ViT_CX() and the third-party k-means of
+    TIS are PARITY UNPINNED (see oracle/vit_cx.py, oracle/tis.py).
   * RISE mask generator: `skimage.transform.resize` is absent and its version is unpinned by the
     reference's requirements.txt -> PARITY UNPINNED at that boundary (see oracle/rise.py).
 

@@ -111,6 +111,23 @@ def main():
     sc = torch.rand(n, device=DEV)
     ms = timeit(lambda: K.rise_accum(grid, sh, sc, (28, 28), H, W, 1.0))
     rep("rise_accum 1000 masks (regen)", n * (64 + 8 + 4) + H * W * 8, ms, f"{n * H * W / ms / 1e6:.1f} G mask-pixels/s (compute-bound)")
+    # K11-K14 (ViT-CX maskers): ViT-B/16 feature maps 768 x 14x14 -> 224x224, 64 clusters
+    fm = torch.randn(768, 14, 14, device=DEV)
+    ms = timeit(lambda: K.up_rownorm(fm, 224, 224))
+    rep("up_rownorm 768 x 14x14->224x224", 768 * (196 + H * W) * 4, ms, "154 MB written once")
+    rows = K.up_rownorm(fm, 224, 224)
+    from xai_engine.vit_cx import cluster_members
+    lab = np.random.default_rng(0).integers(0, 64, 768); lab[:64] = np.arange(64)
+    mem, offs = (torch.from_numpy(a).to(DEV) for a in cluster_members(lab))
+    ms = timeit(lambda: K.cluster_sum(rows, mem, offs))
+    rep("cluster_sum 768 rows -> 64", (768 + 64) * H * W * 4, ms)
+    cs = K.cluster_sum(rows, mem, offs)
+    ms = timeit(lambda: K.rownorm(cs))
+    rep("rownorm 64 x 50176", 64 * H * W * 4 * 3, ms, "2 reads (2nd from L2) + 1 write")
+    noise = torch.randn(64, C, H, W, device=DEV)
+    cm = K.rownorm(cs)
+    ms = timeit(lambda: K.causal_apply(x[0].contiguous(), cm, noise, 0.1))
+    rep("causal_apply 64 masks", 64 * (3 * N + H * W) * 4 + 4 * N, ms, "read noise+masks, write 2N images")
     # K9
     lg = torch.randn(50, 1000, device=DEV)
     ms = timeit(lambda: K.softmax_stats(lg, 3))

@@ -22,10 +22,14 @@ What is pinned (reference file:line in brackets):
                               [VIT_LRP/ViT_ig.py:57-253, VIT_LRP/ViT_explanation_generator.py:139-386]
   cam.npz                     Grad-CAM arithmetic of the reference-owned CAM code (ViT_CX/get_feature_map.py:17-23,
                               ViT_CX/base_cam.py:48-64,129); captum's LayerGradCam itself is absent
+  vit_cx.npz                  ViT-CX norm_matrix / cosine similarity / token reshape and causal_score.forward
+                              [ViT_CX/ViT_CX.py:22-46, ViT_CX/causal_score.py:17-61]
+  tis.npz                     TIS on the mini ViT, every stage except the absent k-means [TIS.py:96-365]
   sweep_small.npz             the 10-key Counter of run_perturbation, driven exactly like
                               XAI_Survey/evaluations/evaluatePerturbation.py:448-497
-The only stub is an inert `cvxopt` module (used by the reference only under
-special_version=True, which is never exercised).
+The only stubs are inert placeholder modules: `cvxopt` (used by the reference only under
+special_version=True, which is never exercised) and, for the ViT-CX / TIS files, the third-party modules they
+import at module level but never reach on the functions called here (see vitcx_fixture / tis_fixture).
 """
 import os
 import sys
@@ -376,6 +380,93 @@ def cam_fixture():
     print("cam.npz", {k: v.shape for k, v in out.items()})
 
 
+def _inert(*names):
+    """Import-time placeholders for third-party modules the reference files import at module level but that the
+    functions called here never touch (nothing in them is callable)."""
+    for name in names:
+        sys.modules.setdefault(name, types.ModuleType(name))
+        if "." in name:
+            parent, child = name.rsplit(".", 1)
+            setattr(sys.modules[parent], child, sys.modules[name])
+
+
+def vitcx_fixture():
+    """ViT-CX pieces that run without torchvision: norm_matrix / get_cos_similar_matrix / reshape_function_vit
+    (ViT_CX/ViT_CX.py:22-46) and causal_score.forward (ViT_CX/causal_score.py:17-61) on the CPU with the tiny
+    classifier + softmax.  ViT_CX() itself needs torchvision's Resize and is not run.  cv2, ttach, skimage and
+    torchvision are inert placeholders (imported at module level there, never called on this path)."""
+    _inert("cv2", "ttach", "skimage", "skimage.transform", "torchvision", "torchvision.transforms")
+    sys.modules["skimage.transform"].resize = None
+    for n in ("Compose", "Normalize", "ToTensor", "Resize"):
+        setattr(sys.modules["torchvision.transforms"], n, None)
+    from util.attribution_methods.ViT_CX import ViT_CX as VCX
+    from util.attribution_methods.ViT_CX.causal_score import causal_score
+    out = {}
+    tokens = randn(500, 2, 17, 12)
+    out["tokens"], out["tokens_reshaped"] = tokens.numpy(), VCX.reshape_function_vit(tokens).contiguous().numpy()
+    act = randn(501, 12, 64) * 3 + 1
+    out["act"], out["act_norm"] = act.numpy(), VCX.norm_matrix(act).numpy()
+    v = VCX.norm_matrix(act)
+    v[3] = 0                                                          # a zero row: 0/0 -> NaN -> 0 (:26)
+    out["cos_in"], out["cos"] = v.numpy().copy(), VCX.get_cos_similar_matrix(v, v).numpy()
+    model = tiny_model(502)
+    out.update(weights_of(model))
+    soft = nn.Sequential(model, nn.Softmax(dim=1))
+    x = randn(503, 1, 3, 32, 32)
+    masks = torch.rand(6, 32, 32, generator=torch.Generator().manual_seed(504))
+    masks[0, :4] = 0                                                  # some exact zeros / ones like normalised masks have
+    masks[1, 5:9] = 1
+    class_p = soft(x)[0].detach().numpy()[2]
+    torch.manual_seed(505)
+    noise = torch.randn([6, 3, 32, 32])                               # the draw causal_score makes first (:27)
+    torch.manual_seed(505)
+    sal = causal_score(soft, (32, 32), gpu_batch=4, device="cpu")(x, masks, class_p)
+    out.update(x=x.numpy(), masks=masks.numpy(), class_p=np.float32(class_p), noise=noise.numpy(), sal=sal.numpy())
+    np.savez(os.path.join(HERE, "vit_cx.npz"), **out)
+    print("vit_cx.npz", {k: v.shape for k, v in out.items() if not k.startswith("w_")})
+
+
+def tis_fixture():
+    """TIS (util/attribution_methods/TIS.py) on the reference's mini hooked ViT, every stage except the k-means
+    (fast_pytorch_kmeans is absent and not even listed in requirements.txt): encoder activations :96-132, binary
+    masks :157-190 from given raw masks, token-sampling scores :244-329, saliency :331-365, and the
+    input-masking branch :192-242 with the zero baseline.  torchvision.models, timm and fast_pytorch_kmeans are
+    inert placeholders (only used in commented-out isinstance checks and in generate_raw_masks)."""
+    _inert("torchvision", "torchvision.models", "timm", "timm.models", "timm.models.vision_transformer", "fast_pytorch_kmeans")
+    sys.modules["torchvision.models"].VisionTransformer = None
+    sys.modules["timm.models.vision_transformer"].VisionTransformer = None
+    sys.modules["fast_pytorch_kmeans"].KMeans = None
+    from functools import partial
+    from util.attribution_methods.TIS import TIS
+    from util.attribution_methods.VIT_LRP.ViT_ig import VisionTransformer
+    g = np.load(os.path.join(HERE, "vit_mini.npz"))
+    model = VisionTransformer(img_size=32, patch_size=8, embed_dim=32, depth=2, num_heads=4, num_classes=10, mlp_ratio=4,
+                              qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6)).eval()
+    model.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_")})
+    x = torch.from_numpy(g["x"])
+    out = {}
+    # (with several ratios the reference can only batch masks of one ratio together: 8 masks, batches of 4)
+    for tag, ratio, bs in (("a", 0.5, 3), ("b", [0.25, 0.75], 4)):
+        tis = TIS(model, n_masks=8, batch_size=bs, tokens_ratio=ratio, normalise=False)
+        with torch.no_grad():
+            pred, acts = tis.get_encoder_activations(x)
+            raw = randn(600, 8, 16)
+            mask_list, idx_list = tis.generate_binary_masks(raw)
+            scores = tis.generate_scores(x, int(pred), idx_list)
+            sal = tis.generate_saliency(x, scores, mask_list)
+            tis.normalise = True
+            sal_n = tis.generate_saliency(x, scores, mask_list)
+        out.update({f"{tag}_pred": np.int64(pred.item()), f"{tag}_acts": acts.numpy(), f"{tag}_raw": raw.numpy(),
+                    f"{tag}_masks": torch.vstack(mask_list).numpy(), f"{tag}_scores": scores.numpy(),
+                    f"{tag}_sal": sal.numpy(), f"{tag}_sal_norm": sal_n.numpy()})
+        if tag == "a":
+            out["a_idx"] = torch.vstack(idx_list).numpy()
+            tis.cur_mask_indices = idx_list[:3]
+            out["a_masked_zero"] = tis.mask_input(x, baseline="zero").numpy()
+    np.savez(os.path.join(HERE, "tis.npz"), **out)
+    print("tis.npz", {k: v.shape for k, v in out.items()})
+
+
 KEYS = ["MAS_ins", "MAS_del", "RISE_ins", "RISE_del", "AIC_ins", "AIC_del", "LERF_res", "MORF_res", "MONO_pos", "MONO_neg"]
 
 
@@ -389,3 +480,5 @@ if __name__ == "__main__":
     sweep_fixture()
     vit_fixture()
     cam_fixture()
+    vitcx_fixture()
+    tis_fixture()

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from conftest import load_golden, rel_inf
-from helpers import tiny_from, logits_fn_of
+from helpers import tiny_from, logits_fn_of, vit_mini_from
 
 
 def _free_port():
@@ -489,7 +489,7 @@ def test_get_VIT_attr_dispatch():
     model = vit_mini_from(g, DEV)
     x = torch.from_numpy(g["x"])
     t = torch.tensor(int(g["target"]))
-    td = {"models": [model, model], "img_hw": 32, "batch_size": 25, "device": DEV, "num_patches": 4}
+    td = {"models": [model, model], "img_hw": 32, "batch_size": 25, "device": DEV, "num_patches": 4, "tis_n_masks": 8}
     key = {"attn": "raw_attn", "grad": "attn_grad", "n_rollout": "naive_rollout", "rollout": "rollout", "t_attn": "tam_final", "attn_ig": "attn_ig"}
     for name in VIT_ATTR_FUNCS:
         got = get_VIT_attr(x.clone(), None, t, dict(td, attr_func=name))
@@ -553,3 +553,114 @@ def test_odd_image_size_end_to_end(attr):
     res = PNP.PositiveNegativePerturbation(model, HW, "lerf", step, torch.zeros_like).single_run(torch.from_numpy(x), sal, DEV, max_batch_size=57)
     want = op.pnp(fn, x, sal, "lerf", step, np.zeros_like, None, 57)
     assert rel_inf(res[1], want[1]) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ f4: ViT-CX and TIS drivers
+def test_causal_score_matches_reference_vectors():
+    from util.attribution_methods.ViT_CX.causal_score import causal_score
+    g = load_golden("vit_cx.npz")
+    model = tiny_from(g, DEV)
+    soft = torch.nn.Sequential(model, torch.nn.Softmax(dim=1))
+    x, masks = torch.from_numpy(g["x"]), torch.from_numpy(g["masks"])
+    torch.manual_seed(505)                                            # the seed the reference ran with: same host noise draw
+    scorer = causal_score(soft, (32, 32), gpu_batch=4, device=DEV)
+    sal_all = scorer(x, masks, g["class_p"])
+    assert sal_all.shape == (10, 32, 32) and rel_inf(sal_all.cpu().numpy(), g["sal"]) <= 1e-5
+    torch.manual_seed(505)
+    row = scorer(x, masks, g["class_p"], target_category=2)
+    assert rel_inf(row.cpu().numpy(), g["sal"][2]) <= 1e-5
+    row = scorer(x, masks, g["class_p"], target_category=7, noise=torch.from_numpy(g["noise"]))
+    assert rel_inf(row.cpu().numpy(), g["sal"][7]) <= 1e-5
+
+
+def test_ViT_CX_end_to_end_vs_oracle():
+    from util.attribution_methods.ViT_CX.ViT_CX import ViT_CX, reshape_function_vit
+    from oracle import vit_cx as ocx
+    gv = load_golden("vit_mini.npz")
+    model = vit_mini_from(gv, DEV)
+    x = torch.from_numpy(gv["x"])
+    layer = model.blocks[-1].norm1
+    noise = torch.randn(32, 3, 32, 32, generator=torch.Generator().manual_seed(9))          # D = 32 feature maps at most
+    # oracle pipeline on the same device model (feature maps and softmax through the model, arithmetic on the CPU)
+    kept = []
+    h = layer.register_forward_hook(lambda m, i, o: kept.append(o.detach()))
+    with torch.no_grad():
+        y = torch.softmax(model(x.to(DEV)), 1)[0].cpu().numpy()
+    h.remove()
+    fmap = ocx.reshape_function_vit(kept[0].cpu().numpy())[0]
+    assert np.array_equal(reshape_function_vit(kept[0]).cpu().numpy()[0], fmap)
+    t = int(np.argmax(y))
+    for thr in (0.1, 0.02):
+        masks, labels, _ = ocx.masks_from_feature_maps(fmap, 32, 32, thr)
+        n = len(masks)
+        soft = lambda b: torch.softmax(model(torch.from_numpy(b).to(DEV)), 1).detach().cpu().numpy()      # noqa: E731
+        want = ocx.causal_score(soft, x.numpy()[0], masks, y[t], noise[:n].numpy(), gpu_batch=5)[t]
+        sal, fm = ViT_CX(model, x, layer, distance_threshold=thr, gpu_batch=5, device=DEV, noise=noise[:n])
+        assert sal.shape == (32, 32) and not sal.is_cuda and fm.shape == (32, 32, 32)
+        assert rel_inf(sal.numpy(), want) <= 1e-5, (thr, n)
+        assert rel_inf(fm.numpy(), ocx.resize_maps(fmap, 32, 32)) <= 2e-6
+    sal2, none = ViT_CX(model, x, layer, target_category=t, gpu_batch=50, device=DEV, noise=noise[:n], distance_threshold=0.02,
+                        return_feature_map=False)
+    assert none is None and rel_inf(sal2.numpy(), want) <= 1e-5
+    sal3, _ = ViT_CX(model, x, layer, device=DEV, device_noise=True, return_feature_map=False)     # device RNG: runs, finite
+    assert torch.isfinite(sal3).all()
+    with pytest.raises(Exception):
+        ViT_CX(model, x, layer, device="cpu")
+
+
+def test_TIS_stages_and_end_to_end():
+    from util.attribution_methods.TIS import TIS
+    from oracle import tis as otis
+    g, gv = load_golden("tis.npz"), load_golden("vit_mini.npz")
+    model = vit_mini_from(gv, DEV)
+    x = torch.from_numpy(gv["x"]).to(DEV)
+    for tag, ratio, bs in (("a", 0.5, 3), ("b", [0.25, 0.75], 4)):
+        raw = torch.from_numpy(g[f"{tag}_raw"]).to(DEV)
+        tis = TIS(model, n_masks=8, batch_size=bs, tokens_ratio=ratio, normalise=False, raw_masks=raw)
+        pred, acts = tis.get_encoder_activations(x)
+        assert int(pred) == int(g[f"{tag}_pred"]) and rel_inf(acts.cpu().numpy(), g[f"{tag}_acts"]) <= 1e-5
+        masks, idx = tis.generate_binary_masks(raw)
+        assert np.array_equal(masks.cpu().numpy(), g[f"{tag}_masks"])
+        scores = tis.generate_scores(x, int(pred), idx)
+        assert rel_inf(scores.cpu().numpy(), g[f"{tag}_scores"]) <= 1e-5
+        assert rel_inf(tis(x).cpu().numpy(), g[f"{tag}_sal"]) <= 1e-5                  # class_idx=None -> predicted class
+        tis.normalise = True
+        assert rel_inf(tis(x, class_idx=int(pred)).cpu().numpy(), g[f"{tag}_sal_norm"]) <= 2e-5
+        if tag == "a":
+            assert np.array_equal(idx[0].cpu().numpy(), g["a_idx"])
+            assert np.array_equal(tis.mask_input(x, idx[0][:3], baseline="zero").cpu().numpy(), g["a_masked_zero"])
+    # k-means path (parity unpinned): runs, deterministic under the NumPy seed, masks cover half the tokens
+    np.random.seed(5)
+    tis = TIS(model, n_masks=6, batch_size=4)
+    a = tis(x)
+    np.random.seed(5)
+    b = TIS(model, n_masks=6, batch_size=4)(x)
+    assert a.shape == (4, 4) and torch.equal(a, b) and float(a.min()) == 0.0 and float(a.max()) == 1.0
+    abl = TIS(model, n_masks=6, batch_size=4, ablation_study=True)(x)
+    assert abl.shape == (4, 4) and torch.isfinite(abl).all()
+    # device k-means vs the oracle restatement on separated clusters, same initial draw
+    from xai_engine.tis import kmeans_centroids
+    rng = np.random.RandomState(3)
+    centres = rng.randn(5, 16).astype(np.float32) * 10
+    pts = np.concatenate([c + 0.01 * rng.randn(40, 16).astype(np.float32) for c in centres])
+    np.random.seed(11)
+    got = kmeans_centroids(torch.from_numpy(pts).to(DEV), 5).cpu().numpy()
+    want = otis.kmeans_centroids(pts, 5, rng=np.random.RandomState(11))
+    assert np.abs(got - want).max() <= 0.05        # same clusters found (a true cluster split between two centroids is ill-conditioned)
+
+
+def test_get_VIT_attr_vitcx_and_tis_dispatch():
+    from xai_engine.sweep import get_VIT_attr
+    gv = load_golden("vit_mini.npz")
+    model = vit_mini_from(gv, DEV)
+    x = torch.from_numpy(gv["x"])
+    td = {"models": [model, model], "img_hw": 32, "batch_size": 25, "device": DEV, "num_patches": 4, "tis_n_masks": 8}
+    np.random.seed(1)
+    torch.manual_seed(1)
+    for name in ("VIT_CX", "TIS"):
+        got = get_VIT_attr(x.clone(), None, torch.tensor(int(gv["target"])), dict(td, attr_func=name))
+        assert got.shape == (32, 32) and got.dtype == np.float32 and np.isfinite(got).all() and (got >= 0).all()
+    # VIT_CX: 3 x min-max normalised map
+    torch.manual_seed(1)
+    got = get_VIT_attr(x.clone(), None, None, dict(td, attr_func="VIT_CX"))
+    assert got.min() == 0.0 and abs(got.max() - 3.0) <= 1e-6

@@ -396,6 +396,47 @@ def test_tis_and_vitcx_accumulators(K):
     assert rel_inf(got, want) <= 5e-6
 
 
+# ------------------------------------------------------------------------------ K11-K14 feature-map maskers (ViT-CX)
+@pytest.mark.parametrize("shape", [(12, 4, 4, 32, 32), (768, 14, 14, 224, 224), (5, 3, 7, 30, 45)])
+def test_up_rownorm_vs_oracle(K, shape):
+    from oracle import vit_cx as ocx
+    R, h, w, H, W = shape
+    fmap = np.random.default_rng(30).standard_normal((R, h, w)).astype(np.float32)
+    got = K.up_rownorm(dev(fmap), H, W)
+    torch.cuda.synchronize()
+    want = ocx.norm_matrix(ocx.resize_maps(fmap, H, W).reshape(R, H * W))
+    assert got.shape == (R, H * W)
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-6              # values in [0,1]: absolute == relative to the row span
+    assert float(got.min()) == 0.0 and float(got.max()) == 1.0
+
+
+def test_rownorm_cluster_sum_and_causal_apply(K):
+    from oracle import vit_cx as ocx
+    from xai_engine.vit_cx import cluster_members
+    g = load_golden("vit_cx.npz")
+    assert rel_inf(K.rownorm(dev(g["act"])).cpu().numpy(), g["act_norm"]) <= 1e-6          # the reference's norm_matrix
+    rng = np.random.default_rng(31)
+    for R, P, n_cl in ((40, 1024, 7), (33, 1001, 5), (768, 224 * 224, 60)):
+        rows = rng.random((R, P)).astype(np.float32)
+        labels = rng.integers(0, n_cl, R)
+        labels[:n_cl] = np.arange(n_cl)                                                      # every cluster non-empty
+        members, offs = cluster_members(labels)
+        got = K.cluster_sum(dev(rows), dev(members), dev(offs)).cpu().numpy()
+        assert np.array_equal(got, ocx.cluster_sums(rows, labels))                           # same order of additions: bit-exact
+    x, masks, noise = g["x"][0], g["masks"].reshape(6, -1), g["noise"]
+    got = K.causal_apply(dev(x), dev(masks), dev(noise), 0.1).cpu().numpy()
+    assert np.array_equal(got, ocx.causal_stack(x, masks, noise))                            # element-wise fp32: bit-exact
+    x7 = rng.standard_normal((3, 30, 45)).astype(np.float32)
+    m7 = rng.random((9, 30 * 45)).astype(np.float32)
+    n7 = rng.standard_normal((9, 3, 30, 45)).astype(np.float32)
+    assert np.array_equal(K.causal_apply(dev(x7), dev(m7), dev(n7), 0.1).cpu().numpy(), ocx.causal_stack(x7, m7, n7))
+    lib = __import__("xai_engine")._lib.load()
+    t = torch.zeros(8, device=DEV)
+    assert lib.xai_up_rownorm_f32(t.data_ptr(), 1, 100, 100, 4, 4, t.data_ptr(), None) == -3
+    assert lib.xai_cluster_sum_f32(t.data_ptr(), None, t.data_ptr(), 1, 4, t.data_ptr(), None) == -1
+    assert lib.xai_causal_apply_f32(t.data_ptr(), t.data_ptr(), t.data_ptr(), 0, 3, 4, 0.1, t.data_ptr(), None) == -2
+
+
 # ------------------------------------------------------------------------------ size-independent properties at full size
 def test_full_size_perturbation_properties(K):
     """224x224, 224 steps, heavy ties (ReLU'd map): every step flips exactly `step` new pixels, the flipped

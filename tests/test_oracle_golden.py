@@ -242,3 +242,58 @@ def test_gradcam_reduce_matches_reference_owned_cam_code():
         assert np.abs(ogc.cam_reduce(act, grad, relu=False) - g[f"{tag}_cam"]).max() / scale <= TOL
         assert np.abs(ogc.cam_reduce(act, grad, relu=True) - g[f"{tag}_cam_relu"]).max() / scale <= TOL
         assert rel_inf(grad.mean(axis=(2, 3), dtype=np.float32), g[f"{tag}_weights"]) <= TOL
+
+
+# ------------------------------------------------------------------ ViT-CX / TIS (f4 maskers)
+def test_vitcx_pieces_match_reference_functions():
+    from oracle import vit_cx as ocx
+    g = load_golden("vit_cx.npz")
+    assert np.array_equal(ocx.reshape_function_vit(g["tokens"]), g["tokens_reshaped"])
+    assert rel_inf(ocx.norm_matrix(g["act"]), g["act_norm"]) <= TOL
+    assert rel_inf(ocx.cos_similar_matrix(g["cos_in"], g["cos_in"]), g["cos"]) <= TOL
+    assert (g["cos"][3] == 0).all() and (g["cos"][:, 3] == 0).all()           # the zero row: NaN -> 0
+    model = tiny_from(g)
+    soft = lambda b: torch.softmax(model(torch.from_numpy(b)), 1).numpy()      # noqa: E731
+    sal = ocx.causal_score(soft, g["x"][0], g["masks"], g["class_p"], g["noise"], gpu_batch=4)
+    assert sal.shape == g["sal"].shape and rel_inf(sal, g["sal"]) <= TOL
+
+
+def test_vitcx_cluster_sums_and_members():
+    from oracle import vit_cx as ocx
+    rng = np.random.default_rng(7)
+    base = rng.random((4, 16, 16)).astype(np.float32)
+    fmap = np.concatenate([base + 0.01 * rng.random((4, 16, 16)).astype(np.float32) for _ in range(3)])   # 3 near-copies of 4 maps
+    masks, labels, rows = ocx.masks_from_feature_maps(fmap, 32, 32, distance_threshold=0.1)
+    assert len(set(labels)) == 4 and masks.shape == (4, 1024)
+    for j in range(4):
+        assert len({labels[j], labels[j + 4], labels[j + 8]}) == 1
+    assert masks.min() == 0 and masks.max() == 1
+
+
+def test_tis_stages_match_reference():
+    from oracle import tis as otis
+    from helpers import vit_mini_from
+    g, gv = load_golden("tis.npz"), load_golden("vit_mini.npz")
+    model = vit_mini_from(gv)
+    pred, acts = otis.encoder_activations(model, gv["x"])
+    assert pred == int(g["a_pred"]) and rel_inf(acts, g["a_acts"]) <= 5e-6
+    for tag, ratio, bs in (("a", 0.5, 3), ("b", [0.25, 0.75], 4)):
+        masks, idx = otis.binary_masks(g[f"{tag}_raw"], ratio)
+        assert np.array_equal(masks, g[f"{tag}_masks"])
+        sc = otis.scores(model, gv["x"], pred, idx, bs)
+        assert rel_inf(sc, g[f"{tag}_scores"]) <= 5e-6
+        assert rel_inf(otis.saliency(g[f"{tag}_scores"], masks, 4, 4, False), g[f"{tag}_sal"]) <= TOL
+        assert rel_inf(otis.saliency(g[f"{tag}_scores"], masks, 4, 4, True), g[f"{tag}_sal_norm"]) <= 1e-5
+        if tag == "a":
+            assert np.array_equal(np.stack(idx), g["a_idx"])
+            assert np.array_equal(otis.mask_input_zero(gv["x"], idx[:3], 8), g["a_masked_zero"])
+
+
+def test_kmeans_restatement_recovers_separated_clusters():
+    from oracle import tis as otis
+    rng = np.random.RandomState(3)
+    centres = rng.randn(5, 16).astype(np.float32) * 10
+    pts = np.concatenate([c + 0.01 * rng.randn(40, 16).astype(np.float32) for c in centres])
+    got = otis.kmeans_centroids(pts, 5, rng=np.random.RandomState(11))
+    d = np.abs(got[:, None] - centres[None]).max(-1)            # every true centre is found by some centroid or merged
+    assert (d.min(0) < 0.1).sum() >= 3
