@@ -89,9 +89,26 @@ def cpu_baseline():
             "sample": f"{n_attr} attributions (IG {STEPS_IG} steps, batch 50, ResNet-50 fp32, 3x224x224) in {dt:.2f} s"}
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torchrun (nothing has touched the
+    GPU yet in this process) and pass its exit code on."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     from xai_engine.prepare import use_tuned_miopen_db
@@ -174,7 +191,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "IG 50 steps, ResNet-50 (seeded random weights), 32-image batch of 3x224x224 per GPU, "
+            "config": {"workload": f"IG 50 steps, ResNet-50 (seeded random weights), {B}-image batch of 3x224x224 per GPU, "
                                    "alpha_star=1, baseline=0", "images_per_gpu": B, "ig_steps": STEPS_IG,
                        "images_per_pass": args.images_per_pass, "classifier_prep": "conv+bn folded" if args.fold_bn else "none", "miopen": "find mode with shipped find-db" if tuned else ("find" if args.miopen_find else "immediate mode"), "parallelism": f"image-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "xai_ig_accum_f32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

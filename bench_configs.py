@@ -34,7 +34,7 @@ def sync(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="1,2,3,4,5")
+    ap.add_argument("--configs", default="1,2,3,4,5,6")
     ap.add_argument("--rise-masks", type=int, default=8000)
     ap.add_argument("--rise-batch", type=int, default=250)
     ap.add_argument("--sweep-images", type=int, default=4, help="images per rank")
