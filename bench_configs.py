@@ -106,8 +106,17 @@ def main():
             from oracle import gradcam as ogc
             act, grad = ogc.layer_act_and_grad(resnet, resnet.layer4, x, int(t))
             err = rel(sal[0].cpu().numpy(), ogc.gradcam_saliency(act, grad, 224, 224)[0])
+        from xai_engine.gradcam import CapturedGradCam
+        cap = CapturedGradCam(resnet, resnet.layer4, x, (224, 224))
+        cap(x, t)
+        sync(dev); t0 = time.perf_counter()
+        for _ in range(20):
+            sal_g = cap(x, t)
+        sync(dev); dtg = (time.perf_counter() - t0) / 20
         emit({"config": 1, "workload": "Grad-CAM ResNet-50 layer4, one 3x224x224 image", "ms_per_attribution": dt * 1e3,
-              "attributions_per_s": 1 / dt, "rel_err_vs_oracle": err, "n_gpus": world})
+              "attributions_per_s": 1 / dt, "rel_err_vs_oracle": err, "ms_per_attribution_hipgraph_replay": dtg * 1e3,
+              "attributions_per_s_hipgraph_replay": 1 / dtg, "hipgraph_vs_eager_rel_diff": rel(sal_g.cpu().numpy(), sal.cpu().numpy()),
+              "n_gpus": world})
 
     if 3 in want:
         N, s, p1 = args.rise_masks, 8, 0.5

@@ -664,3 +664,27 @@ def test_get_VIT_attr_vitcx_and_tis_dispatch():
     torch.manual_seed(1)
     got = get_VIT_attr(x.clone(), None, None, dict(td, attr_func="VIT_CX"))
     assert got.min() == 0.0 and abs(got.max() - 3.0) <= 1e-6
+
+
+def test_captured_gradcam_replays_match_eager():
+    from xai_engine.gradcam import CapturedGradCam, gradcam_saliency
+    from xai_engine.zoo import resnet50
+    model = resnet50(seed=0, width=16, num_classes=20).to(DEV)
+    xs = [torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(40 + i)).to(DEV) for i in range(3)]
+    cap = CapturedGradCam(model, model.layer4, xs[0], (64, 64))
+    for x, t in zip(xs, (3, 11, torch.tensor(7, device=DEV))):          # the target buffer must be honoured on every replay
+        want = gradcam_saliency(model, model.layer4, x, t, (64, 64))
+        got = cap(x, t)
+        assert got.shape == want.shape == (1, 64, 64)
+        assert rel_inf(got.cpu().numpy(), want.cpu().numpy()) <= 1e-5
+    a, b = cap(xs[0], 3), cap(xs[0], 11)
+    assert not torch.equal(a, b)
+    with pytest.raises(ValueError):
+        cap(torch.zeros(2, 3, 64, 64, device=DEV), 0)
+    from xai_engine.sweep import get_CNN_attr
+    td = {"models": [model], "img_hw": 64, "batch_size": 25, "device": DEV, "attr_func": "gc"}
+    eager = get_CNN_attr(xs[1].cpu(), None, torch.tensor(11), dict(td))
+    tdc = dict(td, capture_gradcam=True)
+    for _ in range(2):                                                  # second call replays the cached graph
+        assert rel_inf(get_CNN_attr(xs[1].cpu(), None, torch.tensor(11), tdc), eager) <= 1e-5
+    assert len(tdc["_captured_gradcam"]) == 1
