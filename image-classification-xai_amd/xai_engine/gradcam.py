@@ -59,6 +59,12 @@ def gradcam_saliency(model, layer, inputs, target, out_hw, channels=3):
     return K.bilinear_up(cam[:, 0].contiguous(), out_hw[0], out_hw[1], scale=float(channels), take_abs=True)
 
 
+def _n_classes(model, x):
+    with torch.no_grad():
+        out = model(x)
+    return (out if isinstance(out, torch.Tensor) else out.logits).shape[1]
+
+
 class CapturedGradCam:
     """`gradcam_saliency` for a fixed input shape as ONE hipGraph replay.
 
@@ -72,7 +78,7 @@ class CapturedGradCam:
         sal = cam(x, target)            # (B,H,W) on the device, same values as gradcam_saliency(model, layer, x, target, ...)
     """
 
-    def __init__(self, model, layer, example_input, out_hw, channels=3, warmup=3):
+    def __init__(self, model, layer, example_input, out_hw, channels=3, warmup=3, verify=True):
         if not example_input.is_cuda:
             raise XaiHipError("CapturedGradCam needs its input on a HIP device ('cuda:N')")
         self.dev = example_input.device
@@ -91,6 +97,23 @@ class CapturedGradCam:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.sal = self._run()
+        if verify:
+            self._verify(model, layer, channels)
+
+    def _verify(self, model, layer, channels):
+        """Replay against the eager path on the example input for two classes.  A graph is only as good as every node in
+        it: captured hipMemsetAsync nodes have been observed not to take effect on replay in ROCm 7.2 (see
+        csrc/rank_kernels.hip), and a classifier kernel that relies on one (zero-fill + atomics) would replay wrong --
+        profiles/experiments/exp_captured_ig.py shows exactly that for a whole captured IG attribution."""
+        x = self.x.detach().clone()
+        n_cls = int(_n_classes(model, x))
+        for t in {0, n_cls - 1}:
+            want = gradcam_saliency(model, layer, x, t, self.out_hw, channels)
+            got = self(x, t)
+            scale = float(want.abs().max())
+            if not float((got - want).abs().max()) <= 1e-4 * max(scale, 1e-30):
+                raise XaiHipError("CapturedGradCam: the hipGraph replay does not reproduce the eager Grad-CAM on this model "
+                                  "(a captured node is not replay-safe here); use gradcam_saliency instead")
 
     def _run(self):
         act, grad = self._act_grad()

@@ -27,10 +27,19 @@ def _logits_of(output):
     return output if isinstance(output, torch.Tensor) else output.logits
 
 
+def _select_class(output, target_class):
+    """output[:, target_class].  PyTorch's indexing turns a 0-d device tensor index into a Python int with .item():
+    a host sync after every forward pass (and illegal inside a hipGraph capture); index_select reads the index on the
+    device instead.  Same values, same gradient."""
+    if torch.is_tensor(target_class) and target_class.is_cuda and target_class.dim() == 0:
+        return output.index_select(1, target_class.reshape(1).to(output.device)).squeeze(1)
+    return output[:, target_class]
+
+
 def getGradientsParallel(inputs, model, target_class):
     """d logit[target] / d inputs for a batch; raw logits (reference saliencyMethods.py:209-215)."""
     output = _logits_of(model(inputs))
-    scores = output[:, target_class]
+    scores = _select_class(output, target_class)
     gradients = torch.autograd.grad(scores, inputs, grad_outputs=torch.ones_like(scores))[0]
     return gradients.detach().squeeze(), scores.detach().squeeze()
 
@@ -38,7 +47,7 @@ def getGradientsParallel(inputs, model, target_class):
 def getPredictionParallel(inputs, model, target_class):
     """(reference saliencyMethods.py:218-224)"""
     output = _logits_of(model(inputs))
-    return output[:, target_class].detach().squeeze()
+    return _select_class(output, target_class).detach().squeeze()
 
 
 def input_grad(input, model, target_class):

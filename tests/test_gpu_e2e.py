@@ -688,3 +688,4 @@ def test_captured_gradcam_replays_match_eager():
     for _ in range(2):                                                  # second call replays the cached graph
         assert rel_inf(get_CNN_attr(xs[1].cpu(), None, torch.tensor(11), tdc), eager) <= 1e-5
     assert len(tdc["_captured_gradcam"]) == 1
+
