@@ -75,6 +75,16 @@ def test_product_refuses_cpu_devices_and_never_imports_the_oracle():
         attr.IG(torch.zeros(1, 3, 8, 8), torch.nn.Identity(), 10, 5, 1, 0, "cpu", 0)
     with pytest.raises(XaiHipError):
         MAS.MASMetric(torch.nn.Identity(), 64, "del", 8, torch.zeros_like).single_run(torch.zeros(1, 3, 8, 8), np.zeros((8, 8), np.float32), "cpu")
+    from util.attribution_methods.ViT_CX.ViT_CX import ViT_CX
+    from util.attribution_methods.ViT_CX.causal_score import causal_score
+    from util.attribution_methods.TIS import TIS
+    ident = torch.nn.Identity()
+    with pytest.raises(XaiHipError):
+        ViT_CX(ident, torch.zeros(1, 3, 8, 8), ident, device="cpu")
+    with pytest.raises(XaiHipError):
+        causal_score(ident, (8, 8), device="cpu")(torch.zeros(1, 3, 8, 8), torch.zeros(2, 8, 8), 0.5)
+    with pytest.raises(XaiHipError):
+        TIS(ident)(torch.zeros(1, 3, 8, 8))
     for dirpath, _, files in os.walk(PKG):
         for f in files:
             if f.endswith(".py"):
@@ -235,3 +245,20 @@ def test_sweep_state_checkpoint_roundtrip(tmp_path):
     fresh = SweepState.load_or_new(prefix, 10, 1, 8)                 # a different split must not resume
     assert fresh.used == 0 and fresh.next_pos == 0
     assert SweepState.load_or_new(None, 10, 0, 1).used == 0
+
+
+def test_vitcx_and_tis_host_logic_on_reference_vectors():
+    """The device-independent pieces of the two masker drivers: cluster member lists, token reshape, TIS's binary masks."""
+    from xai_engine.vit_cx import cluster_members, reshape_function_vit
+    from xai_engine.tis import TIS
+    members, offs = cluster_members([2, 0, 1, 0, 2, 2, 1])
+    assert members.tolist() == [1, 3, 2, 6, 0, 4, 5] and offs.tolist() == [0, 2, 4, 7]
+    assert members.dtype == np.int32 and offs.dtype == np.int32
+    g = load_golden("vit_cx.npz")
+    assert np.array_equal(reshape_function_vit(torch.from_numpy(g["tokens"])).numpy(), g["tokens_reshaped"])
+    t = load_golden("tis.npz")
+    for tag, ratio in (("a", 0.5), ("b", [0.25, 0.75])):
+        masks, idx = TIS(None, n_masks=8, tokens_ratio=ratio).generate_binary_masks(torch.from_numpy(t[f"{tag}_raw"]))
+        assert np.array_equal(masks.numpy(), t[f"{tag}_masks"])
+        if tag == "a":
+            assert np.array_equal(idx[0].numpy(), t["a_idx"])
