@@ -150,12 +150,20 @@ __global__ __launch_bounds__(kBlock) void up_rownorm_kernel(const float* __restr
   }
 }
 
-// grid = (slices, rows): every workgroup scans its whole row for min / max (the row is L2 / Infinity-Cache resident
-// after the first touch) and normalises one slice of it, so a handful of rows still fills the chip.
+// Every workgroup scans its whole row for min / max and normalises one slice of it, so a handful of rows still fills
+// the chip.  The `slices` workgroups of a row re-read the same bytes, so they are placed on ONE XCD (workgroups go to
+// XCDs round-robin by linear id, id % 8): the row is fetched into that XCD's L2 once and the other slices hit it.
+// 1-D grid of 8 * slices * ceil(R / 8) workgroups; id -> (row = (id / (8*slices)) * 8 + id % 8, slice = (id / 8) % slices).
+constexpr int kXcds = 8;
 template <bool VEC>
-__global__ __launch_bounds__(kBlock) void rownorm_kernel(const float* __restrict__ x, int64_t P, float* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void rownorm_kernel(const float* __restrict__ x, int R, int64_t P, int slices,
+                                                         float* __restrict__ out) {
   __shared__ float red[2 * (kBlock / 64)];
-  const float* row = x + static_cast<int64_t>(blockIdx.y) * P;
+  const int id = blockIdx.x;
+  const int r = (id / (kXcds * slices)) * kXcds + id % kXcds;
+  const int slice = (id / kXcds) % slices;
+  if (r >= R) return;
+  const float* row = x + static_cast<int64_t>(r) * P;
   float lo = INFINITY, hi = -INFINITY;
   if (VEC) {
     const int64_t P4 = P / 4;
@@ -175,21 +183,21 @@ __global__ __launch_bounds__(kBlock) void rownorm_kernel(const float* __restrict
   }
   block_min_max(lo, hi, red);
   const float span = hi - lo;
-  float* dst = out + static_cast<int64_t>(blockIdx.y) * P;
+  float* dst = out + static_cast<int64_t>(r) * P;
   // `out` may alias `x`: all reads of the scan above are complete for THIS workgroup, but a neighbour slice may still be
   // scanning -- so in-place calls are launched with one slice per row (see the host function).
   if (VEC) {
     const int64_t P4 = P / 4;
-    const int64_t per = (P4 + gridDim.x - 1) / gridDim.x;
-    const int64_t q0 = blockIdx.x * per, q1 = q0 + per < P4 ? q0 + per : P4;
+    const int64_t per = (P4 + slices - 1) / slices;
+    const int64_t q0 = slice * per, q1 = q0 + per < P4 ? q0 + per : P4;
     for (int64_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
       float4 v = ld4(row + 4 * q);
       v.x = (v.x - lo) / span; v.y = (v.y - lo) / span; v.z = (v.z - lo) / span; v.w = (v.w - lo) / span;
       st4(dst + 4 * q, v);
     }
   } else {
-    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
-    const int64_t p0 = blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
+    const int64_t per = (P + slices - 1) / slices;
+    const int64_t p0 = slice * per, p1 = p0 + per < P ? p0 + per : P;
     for (int64_t p = p0 + threadIdx.x; p < p1; p += kBlock) dst[p] = (row[p] - lo) / span;
   }
 }
@@ -264,10 +272,11 @@ XAI_EXPORT int xai_rownorm_f32(const float* x, int R, int64_t P, float* out, xai
     if (slices < 1) slices = 1;
     if (slices > 32) slices = 32;
   }
+  const unsigned grid = static_cast<unsigned>(kXcds * slices * xai_ceil_div(R, kXcds));
   if (P % 4 == 0 && xai_aligned16(x) && xai_aligned16(out))
-    hipLaunchKernelGGL(rownorm_kernel<true>, dim3(slices, R), dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, P, out);
+    hipLaunchKernelGGL(rownorm_kernel<true>, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, R, P, slices, out);
   else
-    hipLaunchKernelGGL(rownorm_kernel<false>, dim3(slices, R), dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, P, out);
+    hipLaunchKernelGGL(rownorm_kernel<false>, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), x, R, P, slices, out);
   return xai_launch_status();
 }
 
