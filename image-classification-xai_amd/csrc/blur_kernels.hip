@@ -1,7 +1,7 @@
 // K7: zero-padded separable blur (the insertion substrate) for gfx950.
 //
-// One workgroup per 16x64 output tile of one channel plane: the (16+2r)x(64+2r) input halo is
-// staged in LDS with zero fill, the horizontal pass writes a (16+2r)x64 LDS intermediate, the
+// One workgroup per THx64 output tile of one channel plane (TH = 16, or 32 for batches): the (TH+2r)x(64+2r)
+// input halo is staged in LDS with zero fill, the horizontal pass writes a (TH+2r)x64 LDS intermediate, the
 // vertical pass writes the tile -- one HBM read and one HBM write per pixel, the 2r-row
 // intermediate never leaves the CU.  Taps are applied in ascending order with separate
 // multiply and add (file is built with -ffp-contract=off).
@@ -9,8 +9,12 @@
 
 namespace {
 
-constexpr int TH = 16, TW = 64, kBlock = 256;
+constexpr int TW = 64, kBlock = 256;
 
+// Both passes slide a 4-wide register window: a lane owns 4 adjacent outputs (along x in the horizontal pass, along y
+// in the vertical one) and reads klen + 3 LDS values for them instead of 4 * klen.  Every output still adds its taps in
+// ascending order with separate multiply and add, so the result is bit-identical to the one-output-per-lane form.
+template <int TH>
 __global__ __launch_bounds__(kBlock) void blur_sep_kernel(const float* __restrict__ x, const float* __restrict__ k1d, int klen,
                                                           int H, int W, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -26,22 +30,39 @@ __global__ __launch_bounds__(kBlock) void blur_sep_kernel(const float* __restric
     tin[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[plane + static_cast<int64_t>(gy) * W + gx] : 0.f;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < IH * TW; i += kBlock) {
-    const int ly = i / TW, lx = i - ly * TW;
-    const float* row = tin + ly * IW + lx;
-    float acc = 0.f;
-    for (int j = 0; j < klen; ++j) acc += k1d[j] * row[j];
-    tmid[i] = acc;
+  for (int i = threadIdx.x; i < IH * (TW / 4); i += kBlock) {
+    const int ly = i / (TW / 4), q = i - ly * (TW / 4);
+    const float* row = tin + ly * IW + 4 * q;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float w0 = row[0], w1 = row[1], w2 = row[2];
+    for (int j = 0; j < klen; ++j) {
+      const float w3 = row[j + 3];
+      const float k = k1d[j];
+      a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
+      w0 = w1; w1 = w2; w2 = w3;
+    }
+    st4(tmid + ly * TW + 4 * q, make_float4(a0, a1, a2, a3));
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TH * TW; i += kBlock) {
-    const int ly = i / TW, lx = i - ly * TW;
-    const int gy = y0 + ly, gx = x0 + lx;
-    if (gy >= H || gx >= W) continue;
-    const float* col = tmid + ly * TW + lx;
-    float acc = 0.f;
-    for (int j = 0; j < klen; ++j) acc += k1d[j] * col[j * TW];
-    out[plane + static_cast<int64_t>(gy) * W + gx] = acc;
+  for (int i = threadIdx.x; i < (TH / 4) * TW; i += kBlock) {
+    const int g = i / TW, lx = i - g * TW;
+    const int gx = x0 + lx;
+    const float* col = tmid + (4 * g) * TW + lx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float w0 = col[0], w1 = col[TW], w2 = col[2 * TW];
+    for (int j = 0; j < klen; ++j) {
+      const float w3 = col[(j + 3) * TW];
+      const float k = k1d[j];
+      a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
+      w0 = w1; w1 = w2; w2 = w3;
+    }
+    if (gx >= W) continue;
+    const int gy = y0 + 4 * g;
+    float* o = out + plane + static_cast<int64_t>(gy) * W + gx;
+    if (gy < H) o[0] = a0;
+    if (gy + 1 < H) o[W] = a1;
+    if (gy + 2 < H) o[2 * static_cast<int64_t>(W)] = a2;
+    if (gy + 3 < H) o[3 * static_cast<int64_t>(W)] = a3;
   }
 }
 
@@ -88,8 +109,20 @@ XAI_EXPORT int xai_blur_sep_f32(const float* x, const float* k1d, int klen, int 
   XAI_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && klen > 0 && (klen & 1), XAI_E_SHAPE);
   XAI_REQUIRE(klen <= 63 && static_cast<int64_t>(B) * C <= 65535, XAI_E_UNSUPPORTED);
   const int r = klen / 2;
-  const size_t lds = static_cast<size_t>((TH + 2 * r) * (TW + 2 * r) + (TH + 2 * r) * TW) * sizeof(float);
-  dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * C);
-  hipLaunchKernelGGL(blur_sep_kernel, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), x, k1d, klen, H, W, out);
+  // 16-row tiles while that is what it takes to give every CU a couple of workgroups (one image: 168 tiles), 32-row tiles
+  // (a third less halo per output) for batches
+  const int64_t tiles16 = static_cast<int64_t>(B) * C * ((W + TW - 1) / TW) * ((H + 15) / 16);
+  const size_t lds32 = static_cast<size_t>((32 + 2 * r) * (TW + 2 * r) + (32 + 2 * r) * TW) * sizeof(float);
+  if (tiles16 >= 8 * static_cast<int64_t>(xai_cu_count()) && lds32 <= 64 * 1024) {
+    constexpr int TH = 32;
+    const size_t lds = lds32;
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * C);
+    hipLaunchKernelGGL(blur_sep_kernel<TH>, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), x, k1d, klen, H, W, out);
+  } else {
+    constexpr int TH = 16;
+    const size_t lds = static_cast<size_t>((TH + 2 * r) * (TW + 2 * r) + (TH + 2 * r) * TW) * sizeof(float);
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * C);
+    hipLaunchKernelGGL(blur_sep_kernel<TH>, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), x, k1d, klen, H, W, out);
+  }
   return xai_launch_status();
 }
