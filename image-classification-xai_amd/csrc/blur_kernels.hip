@@ -3,57 +3,92 @@
 // One workgroup per THx64 output tile of one channel plane (TH = 16, or 32 for batches): the (TH+2r)x(64+2r)
 // input halo is staged in LDS with zero fill, the horizontal pass writes a (TH+2r)x64 LDS intermediate, the
 // vertical pass writes the tile -- one HBM read and one HBM write per pixel, the 2r-row
-// intermediate never leaves the CU.  Taps are applied in ascending order with separate
-// multiply and add (file is built with -ffp-contract=off).
+// intermediate never leaves the CU.  Taps are applied in ascending order, one explicit FMA per tap.
 #include "xai_common.h"
 
 namespace {
 
 constexpr int TW = 64, kBlock = 256;
+static_assert(TW == 64, "the index arithmetic below assumes 64-wide tiles");
 
 // Both passes slide a 4-wide register window: a lane owns 4 adjacent outputs (along x in the horizontal pass, along y
-// in the vertical one) and reads klen + 3 LDS values for them instead of 4 * klen.  Every output still adds its taps in
-// ascending order with separate multiply and add, so the result is bit-identical to the one-output-per-lane form.
+// in the vertical one) and reads klen + 3 LDS values for them instead of 4 * klen.  Every output adds its taps in
+// ascending order with one fused multiply-add per tap -- the same sequence blur_1d_kernel runs, so the fused and the
+// two-pass form agree bit for bit.  (FMA on purpose: the reference is a dense 961-tap conv2d whose summation order
+// cannot be reproduced by any separable form; parity is the 1e-5 bar, and the multiply-add count is what bounds this
+// kernel.)
 template <int TH>
 __global__ __launch_bounds__(kBlock) void blur_sep_kernel(const float* __restrict__ x, const float* __restrict__ k1d, int klen,
                                                           int H, int W, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int r = klen / 2;
   const int IH = TH + 2 * r, IW = TW + 2 * r;
-  float* tin = lds;               // [IH][IW]
-  float* tmid = lds + IH * IW;    // [IH][TW]
+  // odd row pitch: in the horizontal pass a wave reads 4 rows x 16 quads with a 4-float stride inside a row, and an odd
+  // pitch puts the four rows on the four bank residues mod 4 (conflict-free) instead of on the same one
+  const int P = IW | 1;
+  float* tin = lds;                            // [IH][P]
+  float* tmid = lds + ((IH * P + 3) & ~3);     // [IH][TW], 16-byte aligned
   const int64_t plane = static_cast<int64_t>(blockIdx.z) * H * W;
   const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
-  for (int i = threadIdx.x; i < IH * IW; i += kBlock) {
-    const int ly = i / IW, lx = i - ly * IW;
-    const int gy = y0 + ly - r, gx = x0 + lx - r;
-    tin[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[plane + static_cast<int64_t>(gy) * W + gx] : 0.f;
+  // halo staging: a wave per row, lanes along the row (no integer division, coalesced row reads).  Loads are issued in
+  // groups of 8 (4 rows x 2 column steps) into registers before any of them is stored to LDS: with a store between
+  // every two loads the staging was one HBM latency per element and dominated the kernel.
+  {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int kRows = 4, kWaves = kBlock >> 6;
+    for (int base = wave; base < IH; base += kRows * kWaves) {
+      float v[kRows][2];
+#pragma unroll
+      for (int k = 0; k < kRows; ++k) {
+        const int ly = base + k * kWaves;
+        const int gy = y0 + ly - r;
+        const bool row_in = ly < IH && gy >= 0 && gy < H;
+        const float* src = x + plane + static_cast<int64_t>(row_in ? gy : 0) * W;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int lx = lane + 64 * c;
+          const int gx = x0 + lx - r;
+          v[k][c] = (row_in && lx < IW && gx >= 0 && gx < W) ? src[gx] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kRows; ++k) {
+        const int ly = base + k * kWaves;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int lx = lane + 64 * c;
+          if (ly < IH && lx < IW) tin[ly * P + lx] = v[k][c];
+        }
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < IH * (TW / 4); i += kBlock) {
-    const int ly = i / (TW / 4), q = i - ly * (TW / 4);
-    const float* row = tin + ly * IW + 4 * q;
+    const int ly = i >> 4, q = i & 15;                 // TW / 4 == 16 quads per row
+    const float* row = tin + ly * P + 4 * q;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     float w0 = row[0], w1 = row[1], w2 = row[2];
+#pragma unroll 8
     for (int j = 0; j < klen; ++j) {
       const float w3 = row[j + 3];
       const float k = k1d[j];
-      a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
+      a0 = __builtin_fmaf(k, w0, a0); a1 = __builtin_fmaf(k, w1, a1); a2 = __builtin_fmaf(k, w2, a2); a3 = __builtin_fmaf(k, w3, a3);
       w0 = w1; w1 = w2; w2 = w3;
     }
     st4(tmid + ly * TW + 4 * q, make_float4(a0, a1, a2, a3));
   }
   __syncthreads();
   for (int i = threadIdx.x; i < (TH / 4) * TW; i += kBlock) {
-    const int g = i / TW, lx = i - g * TW;
+    const int g = i >> 6, lx = i & 63;                 // TW == 64
     const int gx = x0 + lx;
     const float* col = tmid + (4 * g) * TW + lx;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     float w0 = col[0], w1 = col[TW], w2 = col[2 * TW];
+#pragma unroll 8
     for (int j = 0; j < klen; ++j) {
       const float w3 = col[(j + 3) * TW];
       const float k = k1d[j];
-      a0 += k * w0; a1 += k * w1; a2 += k * w2; a3 += k * w3;
+      a0 = __builtin_fmaf(k, w0, a0); a1 = __builtin_fmaf(k, w1, a1); a2 = __builtin_fmaf(k, w2, a2); a3 = __builtin_fmaf(k, w3, a3);
       w0 = w1; w1 = w2; w2 = w3;
     }
     if (gx >= W) continue;
@@ -80,12 +115,12 @@ __global__ __launch_bounds__(kBlock) void blur_1d_kernel(const float* __restrict
   if (axis == 1) {
     for (int j = 0; j < klen; ++j) {
       const int gx = xx + j - r;
-      acc += k1d[j] * ((gx >= 0 && gx < W) ? x[plane + static_cast<int64_t>(y) * W + gx] : 0.f);
+      acc = __builtin_fmaf(k1d[j], (gx >= 0 && gx < W) ? x[plane + static_cast<int64_t>(y) * W + gx] : 0.f, acc);
     }
   } else {
     for (int j = 0; j < klen; ++j) {
       const int gy = y + j - r;
-      acc += k1d[j] * ((gy >= 0 && gy < H) ? x[plane + static_cast<int64_t>(gy) * W + xx] : 0.f);
+      acc = __builtin_fmaf(k1d[j], (gy >= 0 && gy < H) ? x[plane + static_cast<int64_t>(gy) * W + xx] : 0.f, acc);
     }
   }
   out[plane + p] = acc;
@@ -112,7 +147,7 @@ XAI_EXPORT int xai_blur_sep_f32(const float* x, const float* k1d, int klen, int 
   // 16-row tiles while that is what it takes to give every CU a couple of workgroups (one image: 168 tiles), 32-row tiles
   // (a third less halo per output) for batches
   const int64_t tiles16 = static_cast<int64_t>(B) * C * ((W + TW - 1) / TW) * ((H + 15) / 16);
-  const size_t lds32 = static_cast<size_t>((32 + 2 * r) * (TW + 2 * r) + (32 + 2 * r) * TW) * sizeof(float);
+  const size_t lds32 = static_cast<size_t>((32 + 2 * r) * ((TW + 2 * r) | 1) + 3 + (32 + 2 * r) * TW) * sizeof(float);
   if (tiles16 >= 8 * static_cast<int64_t>(xai_cu_count()) && lds32 <= 64 * 1024) {
     constexpr int TH = 32;
     const size_t lds = lds32;
@@ -120,7 +155,7 @@ XAI_EXPORT int xai_blur_sep_f32(const float* x, const float* k1d, int klen, int 
     hipLaunchKernelGGL(blur_sep_kernel<TH>, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), x, k1d, klen, H, W, out);
   } else {
     constexpr int TH = 16;
-    const size_t lds = static_cast<size_t>((TH + 2 * r) * (TW + 2 * r) + (TH + 2 * r) * TW) * sizeof(float);
+    const size_t lds = static_cast<size_t>((TH + 2 * r) * ((TW + 2 * r) | 1) + 3 + (TH + 2 * r) * TW) * sizeof(float);
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * C);
     hipLaunchKernelGGL(blur_sep_kernel<TH>, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), x, k1d, klen, H, W, out);
   }
