@@ -319,6 +319,10 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     try:
         for pos in range(st.next_pos, len(mine)):
             x = images[mine[pos]]
+            if fused and not x.is_cuda:
+                # one upload through pinned memory, queued behind the previous image's work: a pageable .to(dev) blocks the
+                # host until the stream has drained, which would undo the one-image-deep pipelining
+                x = x.to(torch.float32).contiguous().pin_memory().to(dev, non_blocking=True)
             with torch.no_grad():
                 target = _logits_of(model(x.to(dev))).argmax(1)[0]
             t0 = time.time()
