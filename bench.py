@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--images-per-pass", type=int, default=2, help="images x 50 interpolants per classifier pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", type=int, default=0, help="1 = NHWC classifier weights (slower with MIOpen fp32 on gfx950)")
+    ap.add_argument("--fuse-bn-relu", type=int, default=1, help="1 = run the classifier's eval-mode BatchNorm + ReLU (+ residual add) as one HIP "
+                    "kernel per direction (xai_engine/prepare.py: fuse_bn_relu; every call site is verified bit-identical to the PyTorch "
+                    "kernels before use); the unfused classifier is timed too and reported beside it")
     ap.add_argument("--fold-bn", type=int, default=0, help="1 = fold eval-mode BatchNorm into the convolutions (opt-in, see xai_engine/prepare.py)")
     ap.add_argument("--miopen-find", type=int, default=0, help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find, minutes on a fresh box)")
     ap.add_argument("--miopen-db", type=int, default=1, help="1 = reuse the shipped MIOpen find-db (image-classification-xai_amd/miopen_db, "
@@ -137,14 +140,24 @@ def main():
         model = model.to(memory_format=torch.channels_last)
     B = args.images
     x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(2 + rank)).to(dev)
+    plain_model, prep = model, ("conv+bn folded" if args.fold_bn else "none")
+    if args.fuse_bn_relu and not args.fold_bn and not args.channels_last:
+        from xai_engine.prepare import fuse_bn_relu
+        try:
+            model = fuse_bn_relu(plain_model, verify=x[:2])
+            prep = ("eval-mode BN+ReLU(+residual add) fused into one HIP kernel per direction; every fused call site verified "
+                    "bit-identical (forward and gradients) to the PyTorch kernels on this device before use")
+        except ValueError as e:                       # never silently: say so in the line and run the classifier as given
+            log(f"classifier fusion refused: {e}")
+            prep = f"none (fusion refused: {e})"
     with torch.no_grad():
-        targets = model(x).argmax(1)
+        targets = plain_model(x).argmax(1)
     grads = torch.empty((B, STEPS_IG, C, H, W), dtype=torch.float32, device=dev)
     events = []
 
-    def step(sink=None):
-        return ig_batch(x, model, targets, steps=STEPS_IG, alpha_star=1, baseline=0, images_per_pass=args.images_per_pass,
-                        want_abs=True, grads_buffer=grads, event_sink=sink)
+    def step(sink=None, net=None):
+        return ig_batch(x, net if net is not None else model, targets, steps=STEPS_IG, alpha_star=1, baseline=0,
+                        images_per_pass=args.images_per_pass, want_abs=True, grads_buffer=grads, event_sink=sink)
 
     def fence():
         if world > 1:
@@ -169,6 +182,18 @@ def main():
         dt = float(t[0])
 
     log(f"timed {args.steps} steps in {dt:.3f} s")
+    unfused = None
+    if model is not plain_model and world == 1:       # the same workload on the classifier exactly as given, for the record
+        step(net=plain_model)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step(net=plain_model)
+        fence()
+        du = (time.perf_counter() - t1) / 2
+        unfused = {"value": B / du, "unit": "attributions/s", "ms_per_step": du * 1e3, "steps": 2,
+                   "note": "same run, classifier left as PyTorch modules (no BN/ReLU fusion)"}
+        log(f"unfused classifier: {du * 1e3:.1f} ms/step")
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
     algo_bytes = B * (STEPS_IG + 2) * 4 * N_ELEM + B * H * W * 4      # read S grads + x, write out (+ |sum_c| map); b is a scalar
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -193,7 +218,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"IG 50 steps, ResNet-50 (seeded random weights), {B}-image batch of 3x224x224 per GPU, "
                                    "alpha_star=1, baseline=0", "images_per_gpu": B, "ig_steps": STEPS_IG,
-                       "images_per_pass": args.images_per_pass, "classifier_prep": "conv+bn folded" if args.fold_bn else "none", "miopen": "find mode with shipped find-db" if tuned else ("find" if args.miopen_find else "immediate mode"), "parallelism": f"image-sharded x{world}, no data-path collective"},
+                       "images_per_pass": args.images_per_pass, "classifier_prep": prep, "miopen": "find mode with shipped find-db" if tuned else ("find" if args.miopen_find else "immediate mode"), "parallelism": f"image-sharded x{world}, no data-path collective"},
+            "unfused_classifier": unfused,
             "roofline": {"bound": "hbm", "kernel": "xai_ig_accum_f32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": kern_ms, "launches_timed": len(events)},

@@ -1,0 +1,136 @@
+// Classifier-side fusion (opt-in, xai_engine/prepare.py): eval-mode BatchNorm2d + ReLU (+ residual add) as ONE
+// element-wise kernel per direction instead of PyTorch's three to five.
+//
+//   forward   y  = relu( bn(x) [+ identity] ),   bn(x) = ((x - mean) * invstd) * weight + bias
+//   backward  g1 = y > 0 ? gy : 0;   gx = (g1 * weight) * invstd;   g_identity = g1
+//
+// NCHW, flat indexing: a lane owns 4 consecutive elements when HW % 4 == 0 (they share a channel).  `variant` selects
+// among arithmetically equivalent orderings of the BN expression (bit 0: rsqrt instead of 1/sqrt; bits 1-2: grouping;
+// bit 3: fused multiply-add for the last step); xai_engine/prepare.py uses the one that reproduces PyTorch-ROCm's own
+// eval-mode kernels bit for bit (found by profiles/experiments/exp_bn_variants.py).
+#include "xai_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float inv_std(float var, float eps, int variant) {
+  return (variant & 1) ? rsqrtf(var + eps) : 1.f / sqrtf(var + eps);
+}
+
+__device__ __forceinline__ float bn_value(float x, float mean, float invstd, float w, float b, int variant) {
+  const int grouping = (variant >> 1) & 3;
+  const bool fma = (variant >> 3) & 1;
+  if (grouping == 0) {                       // ((x - mean) * invstd) * w + b
+    const float h = (x - mean) * invstd;
+    return fma ? __builtin_fmaf(h, w, b) : h * w + b;
+  }
+  if (grouping == 1) {                       // (x - mean) * (w * invstd) + b
+    const float s = w * invstd;
+    return fma ? __builtin_fmaf(x - mean, s, b) : (x - mean) * s + b;
+  }
+  const float s = w * invstd;                // x * s + (b - mean * s)
+  const float t = b - mean * s;
+  return fma ? __builtin_fmaf(x, s, t) : x * s + t;
+}
+
+__device__ __forceinline__ float bn_grad(float g, float invstd, float w, int variant) {
+  const int grouping = (variant >> 1) & 3;
+  if (grouping == 0) return (g * w) * invstd;
+  if (grouping == 1) return g * (w * invstd);
+  return (g * invstd) * w;
+}
+
+template <bool VEC, bool ADD, bool RELU>
+__global__ __launch_bounds__(kBlock) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ idt,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                            int variant, int C, int HW, int64_t n, float* __restrict__ y) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * (VEC ? 4 : 1);
+  if (i >= n) return;
+  const int c = static_cast<int>((i / HW) % C);
+  const float m = mean[c], is = inv_std(var[c], eps, variant), wc = w[c], bc = b[c];
+  if (VEC) {
+    const float4 v = ld4(x + i);
+    float4 o = make_float4(bn_value(v.x, m, is, wc, bc, variant), bn_value(v.y, m, is, wc, bc, variant),
+                           bn_value(v.z, m, is, wc, bc, variant), bn_value(v.w, m, is, wc, bc, variant));
+    if (ADD) {
+      const float4 a = ld4(idt + i);
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    st4(y + i, o);
+  } else {
+    float o = bn_value(x[i], m, is, wc, bc, variant);
+    if (ADD) o += idt[i];
+    if (RELU) o = fmaxf(o, 0.f);
+    y[i] = o;
+  }
+}
+
+template <bool VEC, bool ADD>
+__global__ __launch_bounds__(kBlock) void bn_relu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                             const float* __restrict__ w, const float* __restrict__ var, float eps,
+                                                             int variant, int C, int HW, int64_t n, float* __restrict__ gx,
+                                                             float* __restrict__ gid) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * (VEC ? 4 : 1);
+  if (i >= n) return;
+  const int c = static_cast<int>((i / HW) % C);
+  const float is = inv_std(var[c], eps, variant), wc = w[c];
+  if (VEC) {
+    const float4 g = ld4(gy + i), o = ld4(y + i);
+    const float4 g1 = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+    st4(gx + i, make_float4(bn_grad(g1.x, is, wc, variant), bn_grad(g1.y, is, wc, variant), bn_grad(g1.z, is, wc, variant),
+                            bn_grad(g1.w, is, wc, variant)));
+    if (ADD) st4(gid + i, g1);
+  } else {
+    const float g1 = y[i] > 0.f ? gy[i] : 0.f;
+    gx[i] = bn_grad(g1, is, wc, variant);
+    if (ADD) gid[i] = g1;
+  }
+}
+
+}  // namespace
+
+XAI_EXPORT int xai_bn_act_fwd_f32(const float* x, const float* identity, const float* weight, const float* bias, const float* mean,
+                                  const float* var, float eps, int variant, int relu, int N, int C, int HW, float* y,
+                                  xai_stream_t stream) {
+  XAI_REQUIRE_PTR(x); XAI_REQUIRE_PTR(weight); XAI_REQUIRE_PTR(bias); XAI_REQUIRE_PTR(mean); XAI_REQUIRE_PTR(var); XAI_REQUIRE_PTR(y);
+  XAI_REQUIRE(N > 0 && C > 0 && HW > 0 && variant >= 0 && variant < 16, XAI_E_SHAPE);
+  const int64_t n = static_cast<int64_t>(N) * C * HW;
+  const bool vec = HW % 4 == 0 && xai_aligned16(x) && xai_aligned16(y) && (identity == nullptr || xai_aligned16(identity));
+  const unsigned grid = static_cast<unsigned>(xai_ceil_div(n, static_cast<int64_t>(kBlock) * (vec ? 4 : 1)));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define XAI_BN_FWD(V, A, R) \
+  hipLaunchKernelGGL((bn_act_fwd_kernel<V, A, R>), dim3(grid), dim3(kBlock), 0, st, x, identity, weight, bias, mean, var, eps, variant, C, HW, n, y)
+  if (identity != nullptr) {
+    XAI_REQUIRE(relu != 0, XAI_E_UNSUPPORTED);
+    if (vec) XAI_BN_FWD(true, true, true); else XAI_BN_FWD(false, true, true);
+  } else if (relu) {
+    if (vec) XAI_BN_FWD(true, false, true); else XAI_BN_FWD(false, false, true);
+  } else {
+    if (vec) XAI_BN_FWD(true, false, false); else XAI_BN_FWD(false, false, false);
+  }
+#undef XAI_BN_FWD
+  return xai_launch_status();
+}
+
+XAI_EXPORT int xai_bn_relu_bwd_f32(const float* gy, const float* y, const float* weight, const float* var, float eps, int variant, int N,
+                                   int C, int HW, float* gx, float* g_identity, xai_stream_t stream) {
+  XAI_REQUIRE_PTR(gy); XAI_REQUIRE_PTR(y); XAI_REQUIRE_PTR(weight); XAI_REQUIRE_PTR(var); XAI_REQUIRE_PTR(gx);
+  XAI_REQUIRE(N > 0 && C > 0 && HW > 0 && variant >= 0 && variant < 16, XAI_E_SHAPE);
+  const int64_t n = static_cast<int64_t>(N) * C * HW;
+  const bool vec = HW % 4 == 0 && xai_aligned16(gy) && xai_aligned16(y) && xai_aligned16(gx) &&
+                   (g_identity == nullptr || xai_aligned16(g_identity));
+  const unsigned grid = static_cast<unsigned>(xai_ceil_div(n, static_cast<int64_t>(kBlock) * (vec ? 4 : 1)));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define XAI_BN_BWD(V, A) \
+  hipLaunchKernelGGL((bn_relu_bwd_kernel<V, A>), dim3(grid), dim3(kBlock), 0, st, gy, y, weight, var, eps, variant, C, HW, n, gx, g_identity)
+  if (g_identity != nullptr) {
+    if (vec) XAI_BN_BWD(true, true); else XAI_BN_BWD(false, true);
+  } else {
+    if (vec) XAI_BN_BWD(true, false); else XAI_BN_BWD(false, false);
+  }
+#undef XAI_BN_BWD
+  return xai_launch_status();
+}

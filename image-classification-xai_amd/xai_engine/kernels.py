@@ -350,3 +350,32 @@ def causal_apply(x, masks, noise, noise_scale=0.1):
     stack = torch.empty((2 * N, Cc, H, W), dtype=F32, device=x.device)
     _call("xai_causal_apply_f32", x.device, _ptr(x), _ptr(masks), _ptr(noise), N, Cc, H * W, float(noise_scale), _ptr(stack))
     return stack
+
+
+# ------------------------------------------------------------------------------ opt-in classifier-side fusion
+def bn_act_fwd(x, identity, weight, bias, mean, var, eps, variant, relu=True):
+    """y = act(bn(x) [+ identity]) for eval-mode BatchNorm2d statistics; x (N,C,H,W) contiguous."""
+    _need(x, F32, "x")
+    for name, t in (("weight", weight), ("bias", bias), ("mean", mean), ("var", var)):
+        _need(t, F32, name)
+    if identity is not None:
+        _need(identity, F32, "identity")
+        if identity.shape != x.shape:
+            raise ValueError("identity must have the shape of x")
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    y = torch.empty_like(x)
+    _call("xai_bn_act_fwd_f32", x.device, _ptr(x), _ptr(identity), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(var), float(eps),
+          int(variant), int(bool(relu)), N, Cc, HW, _ptr(y))
+    return y
+
+
+def bn_relu_bwd(gy, y, weight, var, eps, variant, want_identity=False):
+    """-> (gx, g_identity or None) for y = relu(bn(x) [+ identity])."""
+    _need(gy, F32, "gy"); _need(y, F32, "y"); _need(weight, F32, "weight"); _need(var, F32, "var")
+    N, Cc = y.shape[0], y.shape[1]
+    HW = y[0, 0].numel()
+    gx = torch.empty_like(y)
+    gid = torch.empty_like(y) if want_identity else None
+    _call("xai_bn_relu_bwd_f32", y.device, _ptr(gy), _ptr(y), _ptr(weight), _ptr(var), float(eps), int(variant), N, Cc, HW, _ptr(gx), _ptr(gid))
+    return gx, gid

@@ -1,5 +1,14 @@
 """Optional classifier preparation for throughput runs (never applied implicitly).
 
+`fuse_bn_relu(model)`: in ResNet-style blocks, eval-mode BatchNorm2d + ReLU (+ the residual add) run as ONE HIP kernel
+per direction (csrc/bnrelu_kernels.hip) instead of three to five PyTorch kernels -- a third of the classifier's GPU
+time in the IG benchmark is spent in those element-wise kernels.  The fused kernels evaluate the expression in the same
+order as PyTorch-ROCm's own (MIOpen inference BN, threshold_backward, batch_norm_elementwise_backward_eval), so logits
+and input gradients are what the unfused classifier computes, bit for bit, given the same convolution outputs (MIOpen's
+convolutions themselves are not run-to-run deterministic); `fuse_bn_relu(..., verify=x)` checks every fused call site
+against the PyTorch kernels on an example batch -- forward and both gradients, bitwise -- and refuses to return a model
+that differs anywhere.
+
 `fold_batchnorm(model)`: eval-mode Conv2d -> BatchNorm2d pairs are folded into one convolution
 (w' = w * gamma/sqrt(var+eps), b' = beta + (b - mean) * gamma/sqrt(var+eps)) by torch.fx.  It is an
 exact algebraic identity, but it changes fp32 rounding inside the classifier (~1e-6 relative on
@@ -38,3 +47,144 @@ def use_tuned_miopen_db(rank=0, src=None):
         return False                 # no writable scratch: stay in immediate mode
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     return True
+
+
+# ------------------------------------------------------------------------------ BN + ReLU (+ add) fusion
+BN_VARIANT = 9      # fma((x - mean) * rsqrt(var + eps), weight, bias); (g * weight) * rsqrt(var + eps): profiles/experiments/exp_bn_variants.py
+
+
+def _bn_tensors(bn, like):
+    import torch
+    w = bn.weight if bn.weight is not None else torch.ones(bn.num_features, device=like.device)
+    b = bn.bias if bn.bias is not None else torch.zeros(bn.num_features, device=like.device)
+    return w.detach().float().contiguous(), b.detach().float().contiguous(), bn.running_mean.float().contiguous(), bn.running_var.float().contiguous()
+
+
+def _make_function():
+    import torch
+    from . import kernels as K
+
+    class BnReluFunction(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, identity, w, b, mean, var, eps):
+            y = K.bn_act_fwd(x.contiguous(), None if identity is None else identity.contiguous(), w, b, mean, var, eps, BN_VARIANT, relu=True)
+            ctx.save_for_backward(y, w, var)
+            ctx.eps, ctx.has_identity = eps, identity is not None
+            return y
+
+        @staticmethod
+        def backward(ctx, gy):
+            y, w, var = ctx.saved_tensors
+            gx, gid = K.bn_relu_bwd(gy.contiguous(), y, w, var, ctx.eps, BN_VARIANT, want_identity=ctx.has_identity)
+            return gx, gid, None, None, None, None, None
+    return BnReluFunction
+
+
+_FN = None
+_CHECK = {"on": False, "sites": 0}
+
+
+def _eager(x, bn, identity):
+    import torch.nn.functional as F
+    out = bn(x)
+    return F.relu(out if identity is None else out + identity)
+
+
+def _check_site(x, bn, identity, fused_fn):
+    """Fused vs PyTorch kernels on the tensors of this call site: forward and both gradients must be bit-identical."""
+    import torch
+    xa, xb = x.detach().clone().requires_grad_(True), x.detach().clone().requires_grad_(True)
+    ia = ib = None
+    if identity is not None:
+        ia, ib = identity.detach().clone().requires_grad_(True), identity.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        ya, yb = _eager(xa, bn, ia), fused_fn(xb, ib)
+        gy = torch.randn_like(ya)
+        ga = torch.autograd.grad(ya, [xa] + ([ia] if ia is not None else []), gy)
+        gb = torch.autograd.grad(yb, [xb] + ([ib] if ib is not None else []), gy)
+    if not (torch.equal(ya, yb) and all(torch.equal(p, q) for p, q in zip(ga, gb))):
+        raise ValueError(f"fuse_bn_relu: fused BN+ReLU differs from the PyTorch kernels for input {tuple(x.shape)}"
+                         f"{' + identity' if identity is not None else ''} (forward equal: {torch.equal(ya, yb)})")
+    _CHECK["sites"] += 1
+
+
+def bn_relu(x, bn, identity=None):
+    """relu(bn(x) [+ identity]) through the fused kernels; falls back to the PyTorch modules whenever the fused form does
+    not apply (training mode, trainable BN parameters, no running statistics, non-fp32 or non-HIP tensors)."""
+    global _FN
+    import torch
+    usable = (not bn.training and bn.track_running_stats and bn.running_mean is not None and x.is_cuda and x.dtype == torch.float32
+              and x.dim() == 4 and not (bn.weight is not None and bn.weight.requires_grad)
+              and not (bn.bias is not None and bn.bias.requires_grad) and (identity is None or identity.shape == x.shape))
+    if not usable:
+        return _eager(x, bn, identity)
+    if _FN is None:
+        _FN = _make_function()
+    w, b, mean, var = _bn_tensors(bn, x)
+    fused_fn = lambda xx, ii: _FN.apply(xx, ii, w, b, mean, var, float(bn.eps))      # noqa: E731
+    if _CHECK["on"]:
+        _check_site(x, bn, identity, fused_fn)
+    return fused_fn(x, identity)
+
+
+def _fused_block_forward(self, x):
+    identity = x if self.downsample is None else self.downsample(x)
+    out = bn_relu(self.conv1(x), self.bn1)
+    if hasattr(self, "conv3"):                      # bottleneck
+        out = bn_relu(self.conv2(out), self.bn2)
+        return bn_relu(self.conv3(out), self.bn3, identity)
+    return bn_relu(self.conv2(out), self.bn2, identity)     # basic block
+
+
+def _fused_resnet_forward(self, x):
+    import torch
+    x = self.maxpool(bn_relu(self.conv1(x), self.bn1))
+    x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+    return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def _is_block(m):
+    import torch.nn as nn
+    names = ("conv1", "bn1", "conv2", "bn2", "relu", "downsample")
+    return all(hasattr(m, n) for n in names) and isinstance(m.bn1, nn.BatchNorm2d) and isinstance(m.relu, nn.ReLU)
+
+
+def fuse_bn_relu(model, verify=None):
+    """Copy of `model` (a ResNet of torchvision's layout: stem conv1/bn1/relu/maxpool, layer1-4 of BasicBlock / Bottleneck
+    modules, avgpool, fc) whose blocks run BN + ReLU (+ add) through the fused kernels.  Parameter names, buffers and hooks
+    are untouched (only `forward` of the blocks and of the stem is replaced).  `verify`: an example input batch on the HIP
+    device; every fused call site is then compared bitwise (forward, gradients) with the PyTorch kernels on the tensors
+    that reach it, else ValueError."""
+    import types
+    import torch
+    import torch.nn as nn
+    m = copy.deepcopy(model).eval()
+    n_blocks = 0
+    for mod in m.modules():
+        if _is_block(mod) and type(mod).forward is not _fused_block_forward:
+            mod.forward = types.MethodType(_fused_block_forward, mod)
+            n_blocks += 1
+    stem = all(hasattr(m, n) for n in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool", "fc"))
+    if stem and isinstance(m.bn1, nn.BatchNorm2d):
+        m.forward = types.MethodType(_fused_resnet_forward, m)
+    if n_blocks == 0:
+        raise ValueError("fuse_bn_relu: no ResNet-style blocks (conv1/bn1/conv2/bn2/relu/downsample) found in the model")
+    for p in m.parameters():
+        p.requires_grad_(False)
+    if verify is not None:
+        # the classifier's convolutions (MIOpen) are not run-to-run deterministic, so two whole-model runs never compare bit
+        # for bit -- not even the original with itself; the check is per call site, on the tensors that reach it
+        _CHECK["on"], _CHECK["sites"] = True, 0
+        find_mode = torch.backends.cudnn.benchmark
+        try:
+            # immediate mode for this one pass: the example batch need not have MIOpen find-db entries, and an exhaustive
+            # search for its convolution shapes would take longer than everything else
+            torch.backends.cudnn.benchmark = False
+            with torch.no_grad():
+                m(verify)
+        finally:
+            torch.backends.cudnn.benchmark = find_mode
+            _CHECK["on"] = False
+        if _CHECK["sites"] == 0:
+            raise ValueError("fuse_bn_relu: no call site used the fused kernels on the example batch (is it on a HIP device, fp32?)")
+    return m

@@ -207,6 +207,23 @@ int xai_cluster_sum_f32(const float* rows, const int32_t* members, const int32_t
 int xai_causal_apply_f32(const float* x, const float* masks, const float* noise, int N, int C,
                          int64_t HW, float noise_scale, float* stack, xai_stream_t stream);
 
+/* ---- opt-in classifier-side fusion (xai_engine/prepare.py: fuse_bn_relu) --------------- */
+
+/* y = act( bn(x) [+ identity] ), eval-mode BatchNorm2d with running statistics; act = ReLU when relu != 0 (required with
+ * an identity).  Not a replacement of a reference expression: the reference's classifiers are torchvision modules
+ * (XAI_Survey/evaluations/evaluatePerturbation.py:627-640) whose BatchNorm2d / ReLU / residual add run as separate
+ * PyTorch kernels; this fuses them.   x, identity, y : [N][C][HW];  weight, bias, mean, var : [C]
+ *   variant : ordering of the arithmetically equivalent BN expression (see csrc/bnrelu_kernels.hip) */
+int xai_bn_act_fwd_f32(const float* x, const float* identity, const float* weight, const float* bias,
+                       const float* mean, const float* var, float eps, int variant, int relu, int N, int C,
+                       int HW, float* y, xai_stream_t stream);
+
+/* backward of the ReLU form, reached through the autograd.grad of saliencyMethods.py:213 (getGradientsParallel):
+ * g1 = y > 0 ? gy : 0;  gx = g1 * weight * invstd;  g_identity (nullable) = g1 */
+int xai_bn_relu_bwd_f32(const float* gy, const float* y, const float* weight, const float* var, float eps,
+                        int variant, int N, int C, int HW, float* gx, float* g_identity,
+                        xai_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

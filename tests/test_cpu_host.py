@@ -262,3 +262,17 @@ def test_vitcx_and_tis_host_logic_on_reference_vectors():
         assert np.array_equal(masks.numpy(), t[f"{tag}_masks"])
         if tag == "a":
             assert np.array_equal(idx[0].numpy(), t["a_idx"])
+
+
+def test_fuse_bn_relu_is_a_no_op_off_the_gpu():
+    """On CPU tensors the fused blocks fall back to the PyTorch modules: identical results, same parameter names."""
+    from xai_engine.prepare import fuse_bn_relu
+    from xai_engine.zoo import resnet50
+    model = resnet50(seed=0, width=8, num_classes=10)
+    fused = fuse_bn_relu(model)
+    assert list(fused.state_dict()) == list(model.state_dict())
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        assert torch.equal(fused(x), model(x))
+    with pytest.raises(ValueError):
+        fuse_bn_relu(torch.nn.Linear(3, 3))

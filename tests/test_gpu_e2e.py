@@ -689,3 +689,63 @@ def test_captured_gradcam_replays_match_eager():
         assert rel_inf(get_CNN_attr(xs[1].cpu(), None, torch.tensor(11), tdc), eager) <= 1e-5
     assert len(tdc["_captured_gradcam"]) == 1
 
+
+
+# ------------------------------------------------------------------------------ opt-in classifier fusion
+def _randomise_bn(model, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+                mod.weight.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+                mod.bias.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+
+
+def test_fused_bn_relu_kernels_bit_identical_to_pytorch():
+    import torch.nn.functional as F
+    from xai_engine import kernels as K
+    from xai_engine.prepare import BN_VARIANT
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for shape in ((4, 16, 28, 28), (3, 8, 7, 7), (2, 5, 9, 11), (1, 64, 56, 56)):         # HW % 4 == 0 and not
+        Cc = shape[1]
+        x, idt, gy = (torch.randn(shape, device=DEV, generator=gen) for _ in range(3))
+        w, var = torch.rand(Cc, device=DEV, generator=gen) + 0.5, torch.rand(Cc, device=DEV, generator=gen) + 0.2
+        b, mean = torch.randn(Cc, device=DEV, generator=gen), torch.randn(Cc, device=DEV, generator=gen)
+        for add in (False, True):
+            xr, ir = x.clone().requires_grad_(True), idt.clone().requires_grad_(True)
+            bn = F.batch_norm(xr, mean, var, w, b, False, 0.0, 1e-5)
+            y = F.relu(bn + ir if add else bn)
+            y.backward(gy)
+            assert torch.equal(K.bn_act_fwd(x, idt if add else None, w, b, mean, var, 1e-5, BN_VARIANT), y.detach())
+            gx, gid = K.bn_relu_bwd(gy, y.detach(), w, var, 1e-5, BN_VARIANT, want_identity=add)
+            assert torch.equal(gx, xr.grad) and (not add or torch.equal(gid, ir.grad))
+        assert torch.equal(K.bn_act_fwd(x, None, w, b, mean, var, 1e-5, BN_VARIANT, relu=False), bn.detach())
+
+
+def test_fuse_bn_relu_model_sites_verified_names_and_hooks_kept():
+    from xai_engine.prepare import fuse_bn_relu
+    from xai_engine.zoo import resnet50
+    from xai_engine.gradcam import gradcam_saliency
+    from xai_engine.ig import IG
+    model = resnet50(seed=0, width=16, num_classes=20).to(DEV)
+    _randomise_bn(model)
+    x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
+    fused = fuse_bn_relu(model, verify=x)                      # every call site bitwise equal to the PyTorch kernels, else ValueError
+    assert list(fused.state_dict()) == list(model.state_dict())
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    oa, ob = model(xa), fused(xb)
+    (ga,), (gb,) = torch.autograd.grad(oa[:, 3].sum(), xa), torch.autograd.grad(ob[:, 3].sum(), xb)
+    # whole-model: equal up to the run-to-run noise of MIOpen's convolutions (the original differs from itself by as much)
+    assert rel_inf(ob.detach().cpu().numpy(), oa.detach().cpu().numpy()) <= 1e-5
+    assert rel_inf(gb.cpu().numpy(), ga.cpu().numpy()) <= 1e-3
+    t = int(oa[0].argmax())
+    cam_a = gradcam_saliency(model, model.layer4, x[:1], t, (64, 64))
+    cam_b = gradcam_saliency(fused, fused.layer4, x[:1], t, (64, 64))          # forward hook on layer4 still fires
+    assert rel_inf(cam_b.cpu().numpy(), cam_a.cpu().numpy()) <= 1e-4
+    ig_a = IG(x[:1], model, 20, 10, 1, 0, DEV, torch.tensor(t))
+    ig_b = IG(x[:1], fused, 20, 10, 1, 0, DEV, torch.tensor(t))
+    assert rel_inf(ig_b.cpu().numpy(), ig_a.cpu().numpy()) <= 2e-3             # ReLU-gate flips from conv noise, as between any two runs
+    with pytest.raises(ValueError):
+        fuse_bn_relu(torch.nn.Sequential(torch.nn.Conv2d(3, 3, 1)).to(DEV))
