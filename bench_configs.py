@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--sweep-images", type=int, default=4, help="images per rank")
     ap.add_argument("--check", type=int, default=1, help="1 = also compare a reduced case with the CPU oracle")
     ap.add_argument("--miopen-db", type=int, default=1, help="1 = MIOpen find mode on the shipped find-db (see xai_engine/prepare.py)")
+    ap.add_argument("--fuse-bn-relu", type=int, default=1, help="1 = ResNet-50's eval BN + ReLU (+ add) through the fused HIP kernels "
+                    "(xai_engine/prepare.py: fuse_bn_relu, verified per call site); 0 = classifier exactly as given")
     ap.add_argument("--record-db", default=None, help="directory to record a find-db into (exhaustive find: minutes)")
     args = ap.parse_args()
     want = {int(c) for c in args.configs.split(",")}
@@ -64,6 +66,8 @@ def main():
 
     def emit(d):
         if rank == 0:
+            if d["config"] in (1, 2, 3, 5):
+                d["classifier_prep"] = prep
             print(json.dumps(d), flush=True)
 
     def rel(a, b):
@@ -71,6 +75,11 @@ def main():
         return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
     resnet = resnet50(seed=0).to(dev) if want & {1, 2, 3, 5} else None
+    prep = "none"
+    if resnet is not None and args.fuse_bn_relu and not args.record_db:
+        from xai_engine.prepare import fuse_bn_relu
+        resnet = fuse_bn_relu(resnet, verify=torch.randn(2, 3, 224, 224, device=dev))
+        prep = "BN+ReLU(+add) fused, call sites verified bit-identical"
 
     if 2 in want:
         xs = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(2))

@@ -36,6 +36,8 @@ def build_parser():
     p.add_argument("--class_map", type=str, default=None, help="correctly_classified_<MODEL>.txt (optional)")
     p.add_argument("--weights", type=str, default=None, help="state_dict file for the chosen architecture")
     p.add_argument("--eight_runs", action="store_true", help="drive the eight single_run calls like the reference instead of the fused sweep")
+    p.add_argument("--fuse_bn_relu", action="store_true", help="CNN models: run eval-mode BatchNorm + ReLU (+ residual add) through the fused "
+                   "HIP kernels (prepare.fuse_bn_relu; every call site is verified bit-identical to the PyTorch kernels first)")
     p.add_argument("--out_dir", type=str, default="pert_test_results")
     p.add_argument("--checkpoint", type=str, default=None, help="path prefix for per-rank resume files (the reference loses a crashed run)")
     return p
@@ -59,6 +61,9 @@ def main(argv=None):
     model = model.to(device).eval()
     for p in model.parameters():
         p.requires_grad_(False)
+    if args.fuse_bn_relu and "VIT" not in args.model:
+        from .prepare import fuse_bn_relu
+        model = fuse_bn_relu(model, verify=torch.randn(2, 3, 224, 224, device=device))
     testing_dict = {"models": [model, model], "imagenet_dataset": args.dataset_path, "normalize": norm, "img_hw": 224,
                     "batch_size": batch_size, "attr_func": args.attr_func, "model_name": args.model,
                     "image_count": args.image_count, "device": str(device), "class_map_path": args.class_map}

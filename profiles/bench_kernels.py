@@ -128,6 +128,21 @@ def main():
     cm = K.rownorm(cs)
     ms = timeit(lambda: K.causal_apply(x[0].contiguous(), cm, noise, 0.1))
     rep("causal_apply 64 masks", 64 * (3 * N + H * W) * 4 + 4 * N, ms, "read noise+masks, write 2N images")
+    # K15 (classifier-side fusion): layer1 activation of the benchmark's pass, 100 x 256 x 56 x 56
+    from xai_engine.prepare import BN_VARIANT
+    act = torch.randn(100, 256, 56, 56, device=DEV); idt = torch.randn_like(act); gy = torch.randn_like(act)
+    wv, bv, mv, vv = (torch.rand(256, device=DEV) + 0.5 for _ in range(4))
+    nb = act.numel() * 4
+    ms = timeit(lambda: K.bn_act_fwd(act, None, wv, bv, mv, vv, 1e-5, BN_VARIANT))
+    rep("bn_act_fwd  relu(bn(x)) 321 MB", 2 * nb, ms)
+    ms = timeit(lambda: K.bn_act_fwd(act, idt, wv, bv, mv, vv, 1e-5, BN_VARIANT))
+    rep("bn_act_fwd  relu(bn(x)+id)", 3 * nb, ms)
+    yv = K.bn_act_fwd(act, idt, wv, bv, mv, vv, 1e-5, BN_VARIANT)
+    ms = timeit(lambda: K.bn_relu_bwd(gy, yv, wv, vv, 1e-5, BN_VARIANT))
+    rep("bn_relu_bwd", 3 * nb, ms)
+    ms = timeit(lambda: K.bn_relu_bwd(gy, yv, wv, vv, 1e-5, BN_VARIANT, want_identity=True))
+    rep("bn_relu_bwd + g_identity", 4 * nb, ms)
+    del act, idt, gy, yv
     # K9
     lg = torch.randn(50, 1000, device=DEV)
     ms = timeit(lambda: K.softmax_stats(lg, 3))
