@@ -155,6 +155,11 @@ def main():
               "masks_per_s": N / dt, "saliency_maps_per_s": 1 / dt, "rel_err_vs_oracle_100_masks": err, "n_gpus": world,
               "collective": "1 all_reduce(SUM) of (224,224) fp64 = 401 KB + broadcast of the mask draw"})
 
+    if want & {4, 6}:
+        # a ViT has one convolution (the patch embedding): MIOpen's search for it costs a minute (its candidates include a
+        # naive kernel at 7 s per trial) and buys nothing -- immediate mode for the ViT configurations
+        torch.backends.cudnn.benchmark = False
+
     if 4 in want:
         vit = vit_base_patch16_224(seed=0).to(dev)
         x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(4))

@@ -379,3 +379,12 @@ def bn_relu_bwd(gy, y, weight, var, eps, variant, want_identity=False):
     gid = torch.empty_like(y) if want_identity else None
     _call("xai_bn_relu_bwd_f32", y.device, _ptr(gy), _ptr(y), _ptr(weight), _ptr(var), float(eps), int(variant), N, Cc, HW, _ptr(gx), _ptr(gid))
     return gx, gid
+
+
+def maxpool_bwd(gy, indices, H, W, kernel, stride, pad):
+    """gy, indices (N,C,PH,PW) (indices int64 from F.max_pool2d(..., return_indices=True)) -> gx (N,C,H,W)."""
+    _need(gy, F32, "gy"); _need(indices, torch.int64, "indices")
+    N, Cc, PH, PW = gy.shape
+    gx = torch.empty((N, Cc, int(H), int(W)), dtype=F32, device=gy.device)
+    _call("xai_maxpool_bwd_f32", gy.device, _ptr(gy), _ptr(indices), N * Cc, int(H), int(W), PH, PW, int(kernel), int(stride), int(pad), _ptr(gx))
+    return gx

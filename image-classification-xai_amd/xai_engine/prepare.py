@@ -136,9 +136,58 @@ def _fused_block_forward(self, x):
     return bn_relu(self.conv2(out), self.bn2, identity)     # basic block
 
 
+_POOL_FN = None
+
+
+def max_pool(x, pool):
+    """pool(x) with PyTorch's forward (and its arg-max indices) and the fused library's backward (same accumulation order as
+    PyTorch's max_pool_backward_nchw, a quarter of its time); anything but a plain square MaxPool2d takes the module."""
+    global _POOL_FN
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    def one(v):
+        return v if isinstance(v, int) else (v[0] if v[0] == v[1] else None)
+    k, s, p, d = one(pool.kernel_size), one(pool.stride), one(pool.padding), one(pool.dilation)
+    applicable = (isinstance(pool, nn.MaxPool2d) and None not in (k, s, p) and d == 1 and not pool.ceil_mode and not pool.return_indices
+                  and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4)
+    if not applicable or not (_CHECK["on"] or (x.requires_grad and torch.is_grad_enabled())):
+        return pool(x)                                   # forward-only passes gain nothing from the custom backward
+    if _POOL_FN is None:
+        from . import kernels as K
+
+        class MaxPoolFunction(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, inp, kk, ss, pp):
+                out, idx = F.max_pool2d(inp, kk, ss, pp, 1, False, True)
+                ctx.save_for_backward(idx)
+                ctx.geom = (inp.shape[2], inp.shape[3], kk, ss, pp)
+                return out
+
+            @staticmethod
+            def backward(ctx, gy):
+                (idx,) = ctx.saved_tensors
+                H, W, kk, ss, pp = ctx.geom
+                return K.maxpool_bwd(gy.contiguous(), idx, H, W, kk, ss, pp), None, None, None
+        _POOL_FN = MaxPoolFunction
+    if _CHECK["on"]:
+        xa, xb = x.detach().clone().requires_grad_(True), x.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            ya, yb = pool(xa), _POOL_FN.apply(xb, k, s, p)
+            gy = torch.randn_like(ya)
+            (ga,), (gb,) = torch.autograd.grad(ya, xa, gy), torch.autograd.grad(yb, xb, gy)
+        if not (torch.equal(ya, yb) and torch.equal(ga, gb)):
+            raise ValueError(f"fuse_bn_relu: max-pool backward differs from PyTorch's for input {tuple(x.shape)}")
+        _CHECK["sites"] += 1
+    if not (x.requires_grad and torch.is_grad_enabled()):
+        return pool(x)
+    return _POOL_FN.apply(x, k, s, p)
+
+
 def _fused_resnet_forward(self, x):
     import torch
-    x = self.maxpool(bn_relu(self.conv1(x), self.bn1))
+    x = max_pool(bn_relu(self.conv1(x), self.bn1), self.maxpool)
     x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
     return self.fc(torch.flatten(self.avgpool(x), 1))
 

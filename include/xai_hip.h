@@ -224,6 +224,12 @@ int xai_bn_relu_bwd_f32(const float* gy, const float* y, const float* weight, co
                         int variant, int N, int C, int HW, float* gx, float* g_identity,
                         xai_stream_t stream);
 
+/* MaxPool2d backward from the forward's arg-max indices (int64, h * W + w within a plane), windows added in (ph, pw)
+ * ascending order like PyTorch's max_pool_backward_nchw -> bit-identical; the stem of the classifiers instantiated at
+ * XAI_Survey/evaluations/evaluatePerturbation.py:627-640.   gy, indices : [planes][PH*PW];  gx : [planes][H*W] */
+int xai_maxpool_bwd_f32(const float* gy, const int64_t* indices, int planes, int H, int W, int PH, int PW,
+                        int kernel, int stride, int pad, float* gx, xai_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

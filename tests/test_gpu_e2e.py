@@ -749,3 +749,14 @@ def test_fuse_bn_relu_model_sites_verified_names_and_hooks_kept():
     assert rel_inf(ig_b.cpu().numpy(), ig_a.cpu().numpy()) <= 2e-3             # ReLU-gate flips from conv noise, as between any two runs
     with pytest.raises(ValueError):
         fuse_bn_relu(torch.nn.Sequential(torch.nn.Conv2d(3, 3, 1)).to(DEV))
+    # the stem's max-pool backward: bit-identical to PyTorch's, also for odd sizes and other geometries
+    from xai_engine.prepare import max_pool
+    for shape, (k, s_, p) in (((3, 5, 112, 112), (3, 2, 1)), ((2, 4, 31, 45), (3, 2, 1)), ((2, 3, 20, 20), (2, 2, 0)), ((1, 2, 17, 9), (3, 1, 1))):
+        pool = torch.nn.MaxPool2d(k, s_, p)
+        xa = torch.randn(shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7)).round(decimals=1)   # ties on purpose
+        xb = xa.clone()
+        xa.requires_grad_(True); xb.requires_grad_(True)
+        ya, yb = pool(xa), max_pool(xb, pool)
+        gy = torch.randn_like(ya)
+        (ga,), (gb,) = torch.autograd.grad(ya, xa, gy), torch.autograd.grad(yb, xb, gy)
+        assert torch.equal(ya, yb) and torch.equal(ga, gb), shape
