@@ -144,7 +144,7 @@ def main():
     if args.fuse_bn_relu and not args.fold_bn and not args.channels_last:
         from xai_engine.prepare import fuse_bn_relu
         try:
-            model = fuse_bn_relu(plain_model, verify=x[:2])
+            model = fuse_bn_relu(plain_model, verify=x[:2], fork_residual=True)
             prep = ("eval-mode BN+ReLU(+residual add) fused into one HIP kernel per direction; every fused call site verified "
                     "bit-identical (forward and gradients) to the PyTorch kernels on this device before use")
         except ValueError as e:                       # never silently: say so in the line and run the classifier as given

@@ -78,7 +78,7 @@ def main():
     prep = "none"
     if resnet is not None and args.fuse_bn_relu and not args.record_db:
         from xai_engine.prepare import fuse_bn_relu
-        resnet = fuse_bn_relu(resnet, verify=torch.randn(2, 3, 224, 224, device=dev))
+        resnet = fuse_bn_relu(resnet, verify=torch.randn(2, 3, 224, 224, device=dev), fork_residual=True)
         prep = "BN+ReLU(+add) fused, call sites verified bit-identical"
 
     if 2 in want:

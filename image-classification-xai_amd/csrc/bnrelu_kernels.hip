@@ -41,68 +41,105 @@ __device__ __forceinline__ float bn_grad(float g, float invstd, float w, int var
   return (g * invstd) * w;
 }
 
+// second BN (bn2.*, nullable as a set): the identity operand is itself a raw convolution output that still needs its own
+// eval-mode BatchNorm -- the down-sample branch of a residual block: y = relu(bn(x) + bn2(identity)).
+struct BnParams {
+  const float* w;
+  const float* b;
+  const float* mean;
+  const float* var;
+  float eps;
+};
+
 template <bool VEC, bool ADD, bool RELU>
 __global__ __launch_bounds__(kBlock) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ idt,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                                            int variant, int C, int HW, int64_t n, float* __restrict__ y) {
+                                                            BnParams bn2, int variant, int C, int HW, int64_t n, float* __restrict__ y) {
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * (VEC ? 4 : 1);
   if (i >= n) return;
   const int c = static_cast<int>((i / HW) % C);
   const float m = mean[c], is = inv_std(var[c], eps, variant), wc = w[c], bc = b[c];
+  const bool second = ADD && bn2.w != nullptr;
+  float m2 = 0.f, is2 = 1.f, w2 = 1.f, b2 = 0.f;
+  if (second) { m2 = bn2.mean[c]; is2 = inv_std(bn2.var[c], bn2.eps, variant); w2 = bn2.w[c]; b2 = bn2.b[c]; }
   if (VEC) {
     const float4 v = ld4(x + i);
     float4 o = make_float4(bn_value(v.x, m, is, wc, bc, variant), bn_value(v.y, m, is, wc, bc, variant),
                            bn_value(v.z, m, is, wc, bc, variant), bn_value(v.w, m, is, wc, bc, variant));
     if (ADD) {
-      const float4 a = ld4(idt + i);
+      float4 a = ld4(idt + i);
+      if (second)
+        a = make_float4(bn_value(a.x, m2, is2, w2, b2, variant), bn_value(a.y, m2, is2, w2, b2, variant),
+                        bn_value(a.z, m2, is2, w2, b2, variant), bn_value(a.w, m2, is2, w2, b2, variant));
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
     if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     st4(y + i, o);
   } else {
     float o = bn_value(x[i], m, is, wc, bc, variant);
-    if (ADD) o += idt[i];
+    if (ADD) o += second ? bn_value(idt[i], m2, is2, w2, b2, variant) : idt[i];
     if (RELU) o = fmaxf(o, 0.f);
     y[i] = o;
   }
 }
 
+// gy2 (nullable): a second incoming gradient of the same output, summed first -- the residual join (the block output feeds
+// the next block's first convolution AND its identity path), which autograd would otherwise add in a kernel of its own.
 template <bool VEC, bool ADD>
-__global__ __launch_bounds__(kBlock) void bn_relu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
-                                                             const float* __restrict__ w, const float* __restrict__ var, float eps,
-                                                             int variant, int C, int HW, int64_t n, float* __restrict__ gx,
+__global__ __launch_bounds__(kBlock) void bn_relu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ gy2,
+                                                             const float* __restrict__ y, const float* __restrict__ w,
+                                                             const float* __restrict__ var, float eps, BnParams bn2, int variant,
+                                                             int C, int HW, int64_t n, float* __restrict__ gx,
                                                              float* __restrict__ gid) {
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * (VEC ? 4 : 1);
   if (i >= n) return;
   const int c = static_cast<int>((i / HW) % C);
   const float is = inv_std(var[c], eps, variant), wc = w[c];
+  const bool second = ADD && bn2.w != nullptr;          // g_identity then goes through the identity operand's own BatchNorm
+  float is2 = 1.f, w2 = 1.f;
+  if (second) { is2 = inv_std(bn2.var[c], bn2.eps, variant); w2 = bn2.w[c]; }
   if (VEC) {
-    const float4 g = ld4(gy + i), o = ld4(y + i);
+    float4 g = ld4(gy + i);
+    if (gy2 != nullptr) {
+      const float4 h = ld4(gy2 + i);
+      g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
+    }
+    const float4 o = ld4(y + i);
     const float4 g1 = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
     st4(gx + i, make_float4(bn_grad(g1.x, is, wc, variant), bn_grad(g1.y, is, wc, variant), bn_grad(g1.z, is, wc, variant),
                             bn_grad(g1.w, is, wc, variant)));
-    if (ADD) st4(gid + i, g1);
+    if (ADD)
+      st4(gid + i, second ? make_float4(bn_grad(g1.x, is2, w2, variant), bn_grad(g1.y, is2, w2, variant), bn_grad(g1.z, is2, w2, variant),
+                                        bn_grad(g1.w, is2, w2, variant))
+                          : g1);
   } else {
-    const float g1 = y[i] > 0.f ? gy[i] : 0.f;
+    float g = gy[i];
+    if (gy2 != nullptr) g += gy2[i];
+    const float g1 = y[i] > 0.f ? g : 0.f;
     gx[i] = bn_grad(g1, is, wc, variant);
-    if (ADD) gid[i] = g1;
+    if (ADD) gid[i] = second ? bn_grad(g1, is2, w2, variant) : g1;
   }
 }
 
 }  // namespace
 
 XAI_EXPORT int xai_bn_act_fwd_f32(const float* x, const float* identity, const float* weight, const float* bias, const float* mean,
-                                  const float* var, float eps, int variant, int relu, int N, int C, int HW, float* y,
+                                  const float* var, float eps, const float* weight2, const float* bias2, const float* mean2,
+                                  const float* var2, float eps2, int variant, int relu, int N, int C, int HW, float* y,
                                   xai_stream_t stream) {
   XAI_REQUIRE_PTR(x); XAI_REQUIRE_PTR(weight); XAI_REQUIRE_PTR(bias); XAI_REQUIRE_PTR(mean); XAI_REQUIRE_PTR(var); XAI_REQUIRE_PTR(y);
   XAI_REQUIRE(N > 0 && C > 0 && HW > 0 && variant >= 0 && variant < 16, XAI_E_SHAPE);
+  if (weight2 != nullptr) {
+    XAI_REQUIRE_PTR(identity); XAI_REQUIRE_PTR(bias2); XAI_REQUIRE_PTR(mean2); XAI_REQUIRE_PTR(var2);
+  }
+  const BnParams bn2{weight2, bias2, mean2, var2, eps2};
   const int64_t n = static_cast<int64_t>(N) * C * HW;
   const bool vec = HW % 4 == 0 && xai_aligned16(x) && xai_aligned16(y) && (identity == nullptr || xai_aligned16(identity));
   const unsigned grid = static_cast<unsigned>(xai_ceil_div(n, static_cast<int64_t>(kBlock) * (vec ? 4 : 1)));
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define XAI_BN_FWD(V, A, R) \
-  hipLaunchKernelGGL((bn_act_fwd_kernel<V, A, R>), dim3(grid), dim3(kBlock), 0, st, x, identity, weight, bias, mean, var, eps, variant, C, HW, n, y)
+  hipLaunchKernelGGL((bn_act_fwd_kernel<V, A, R>), dim3(grid), dim3(kBlock), 0, st, x, identity, weight, bias, mean, var, eps, bn2, variant, C, HW, n, y)
   if (identity != nullptr) {
     XAI_REQUIRE(relu != 0, XAI_E_UNSUPPORTED);
     if (vec) XAI_BN_FWD(true, true, true); else XAI_BN_FWD(false, true, true);
@@ -115,17 +152,22 @@ XAI_EXPORT int xai_bn_act_fwd_f32(const float* x, const float* identity, const f
   return xai_launch_status();
 }
 
-XAI_EXPORT int xai_bn_relu_bwd_f32(const float* gy, const float* y, const float* weight, const float* var, float eps, int variant, int N,
-                                   int C, int HW, float* gx, float* g_identity, xai_stream_t stream) {
+XAI_EXPORT int xai_bn_relu_bwd_f32(const float* gy, const float* gy2, const float* y, const float* weight, const float* var, float eps,
+                                   const float* weight2, const float* var2, float eps2, int variant, int N, int C, int HW, float* gx,
+                                   float* g_identity, xai_stream_t stream) {
   XAI_REQUIRE_PTR(gy); XAI_REQUIRE_PTR(y); XAI_REQUIRE_PTR(weight); XAI_REQUIRE_PTR(var); XAI_REQUIRE_PTR(gx);
   XAI_REQUIRE(N > 0 && C > 0 && HW > 0 && variant >= 0 && variant < 16, XAI_E_SHAPE);
   const int64_t n = static_cast<int64_t>(N) * C * HW;
+  if (weight2 != nullptr) {
+    XAI_REQUIRE_PTR(g_identity); XAI_REQUIRE_PTR(var2);
+  }
+  const BnParams bn2{weight2, nullptr, nullptr, var2, eps2};
   const bool vec = HW % 4 == 0 && xai_aligned16(gy) && xai_aligned16(y) && xai_aligned16(gx) &&
-                   (g_identity == nullptr || xai_aligned16(g_identity));
+                   (g_identity == nullptr || xai_aligned16(g_identity)) && (gy2 == nullptr || xai_aligned16(gy2));
   const unsigned grid = static_cast<unsigned>(xai_ceil_div(n, static_cast<int64_t>(kBlock) * (vec ? 4 : 1)));
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define XAI_BN_BWD(V, A) \
-  hipLaunchKernelGGL((bn_relu_bwd_kernel<V, A>), dim3(grid), dim3(kBlock), 0, st, gy, y, weight, var, eps, variant, C, HW, n, gx, g_identity)
+  hipLaunchKernelGGL((bn_relu_bwd_kernel<V, A>), dim3(grid), dim3(kBlock), 0, st, gy, gy2, y, weight, var, eps, bn2, variant, C, HW, n, gx, g_identity)
   if (g_identity != nullptr) {
     if (vec) XAI_BN_BWD(true, true); else XAI_BN_BWD(false, true);
   } else {

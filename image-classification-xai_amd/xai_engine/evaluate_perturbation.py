@@ -63,7 +63,7 @@ def main(argv=None):
         p.requires_grad_(False)
     if args.fuse_bn_relu and "VIT" not in args.model:
         from .prepare import fuse_bn_relu
-        model = fuse_bn_relu(model, verify=torch.randn(2, 3, 224, 224, device=device))
+        model = fuse_bn_relu(model, verify=torch.randn(2, 3, 224, 224, device=device), fork_residual=True)
     testing_dict = {"models": [model, model], "imagenet_dataset": args.dataset_path, "normalize": norm, "img_hw": 224,
                     "batch_size": batch_size, "attr_func": args.attr_func, "model_name": args.model,
                     "image_count": args.image_count, "device": str(device), "class_map_path": args.class_map}

@@ -12,6 +12,19 @@ from . import kernels as K
 from ._lib import XaiHipError
 
 
+def _grad_of_activation(score, act):
+    """d score / d act.  A classifier prepared with prepare.fuse_bn_relu(fork_residual=True) hands a block output on as two
+    tensors on one storage (act and act._xai_alias); the gradient of the activation is the sum over both handles."""
+    alias = getattr(act, "_xai_alias", None)
+    if alias is None:
+        (grad,) = torch.autograd.grad(score, act)
+        return grad
+    ga, gb = torch.autograd.grad(score, [act, alias], allow_unused=True)
+    if ga is None or gb is None:
+        return ga if gb is None else gb
+    return ga + gb
+
+
 class LayerGradCam:
     def __init__(self, forward_func, layer, device_ids=None):
         self.forward_func = forward_func
@@ -32,7 +45,7 @@ class LayerGradCam:
                     score = out.gather(1, target.reshape(-1, 1).to(out.device)).sum()
                 else:
                     score = out[:, int(target)].sum()
-                (grad,) = torch.autograd.grad(score, kept["act"])
+                grad = _grad_of_activation(score, kept["act"])
         finally:
             handle.remove()
         return kept["act"].detach(), grad.detach()
@@ -128,7 +141,7 @@ class CapturedGradCam:
                 out = self._cam.forward_func(self.x)
                 out = out if isinstance(out, torch.Tensor) else out.logits
                 score = out.gather(1, self.target.view(-1, 1)).sum()        # target read from the static device buffer
-                (grad,) = torch.autograd.grad(score, kept["act"])
+                grad = _grad_of_activation(score, kept["act"])
         finally:
             handle.remove()
         return kept["act"].detach(), grad.detach()

@@ -353,8 +353,9 @@ def causal_apply(x, masks, noise, noise_scale=0.1):
 
 
 # ------------------------------------------------------------------------------ opt-in classifier-side fusion
-def bn_act_fwd(x, identity, weight, bias, mean, var, eps, variant, relu=True):
-    """y = act(bn(x) [+ identity]) for eval-mode BatchNorm2d statistics; x (N,C,H,W) contiguous."""
+def bn_act_fwd(x, identity, weight, bias, mean, var, eps, variant, relu=True, bn2=None):
+    """y = act(bn(x) [+ identity]) for eval-mode BatchNorm2d statistics; x (N,C,H,W) contiguous.
+    bn2 = (weight, bias, mean, var, eps): the identity operand gets its own BatchNorm first (down-sample branch)."""
     _need(x, F32, "x")
     for name, t in (("weight", weight), ("bias", bias), ("mean", mean), ("var", var)):
         _need(t, F32, name)
@@ -362,22 +363,40 @@ def bn_act_fwd(x, identity, weight, bias, mean, var, eps, variant, relu=True):
         _need(identity, F32, "identity")
         if identity.shape != x.shape:
             raise ValueError("identity must have the shape of x")
+    w2 = b2 = m2 = v2 = None
+    eps2 = 0.0
+    if bn2 is not None:
+        w2, b2, m2, v2, eps2 = bn2
+        for name, t in (("weight2", w2), ("bias2", b2), ("mean2", m2), ("var2", v2)):
+            _need(t, F32, name)
     N, Cc = x.shape[0], x.shape[1]
     HW = x[0, 0].numel()
     y = torch.empty_like(x)
     _call("xai_bn_act_fwd_f32", x.device, _ptr(x), _ptr(identity), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(var), float(eps),
-          int(variant), int(bool(relu)), N, Cc, HW, _ptr(y))
+          _ptr(w2), _ptr(b2), _ptr(m2), _ptr(v2), float(eps2), int(variant), int(bool(relu)), N, Cc, HW, _ptr(y))
     return y
 
 
-def bn_relu_bwd(gy, y, weight, var, eps, variant, want_identity=False):
-    """-> (gx, g_identity or None) for y = relu(bn(x) [+ identity])."""
+def bn_relu_bwd(gy, y, weight, var, eps, variant, want_identity=False, gy2=None, bn2=None):
+    """-> (gx, g_identity or None) for y = relu(bn(x) [+ identity]); the incoming gradient is gy (+ gy2).
+    bn2 = (weight2, var2, eps2): g_identity is the gradient of the identity operand BEFORE its own BatchNorm."""
     _need(gy, F32, "gy"); _need(y, F32, "y"); _need(weight, F32, "weight"); _need(var, F32, "var")
+    if gy2 is not None:
+        _need(gy2, F32, "gy2")
+        if gy2.shape != gy.shape:
+            raise ValueError("gy2 must have the shape of gy")
+    w2 = v2 = None
+    eps2 = 0.0
+    if bn2 is not None:
+        w2, v2, eps2 = bn2
+        _need(w2, F32, "weight2"); _need(v2, F32, "var2")
+        want_identity = True
     N, Cc = y.shape[0], y.shape[1]
     HW = y[0, 0].numel()
     gx = torch.empty_like(y)
     gid = torch.empty_like(y) if want_identity else None
-    _call("xai_bn_relu_bwd_f32", y.device, _ptr(gy), _ptr(y), _ptr(weight), _ptr(var), float(eps), int(variant), N, Cc, HW, _ptr(gx), _ptr(gid))
+    _call("xai_bn_relu_bwd_f32", y.device, _ptr(gy), _ptr(gy2), _ptr(y), _ptr(weight), _ptr(var), float(eps), _ptr(w2), _ptr(v2), float(eps2),
+          int(variant), N, Cc, HW, _ptr(gx), _ptr(gid))
     return gx, gid
 
 

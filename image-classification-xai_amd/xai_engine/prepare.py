@@ -65,18 +65,29 @@ def _make_function():
     from . import kernels as K
 
     class BnReluFunction(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, identity, w, b, mean, var, eps):
-            y = K.bn_act_fwd(x.contiguous(), None if identity is None else identity.contiguous(), w, b, mean, var, eps, BN_VARIANT, relu=True)
-            ctx.save_for_backward(y, w, var)
-            ctx.eps, ctx.has_identity = eps, identity is not None
-            return y
+        """relu(bn(x) [+ identity]).  With `fork` the output is returned twice, as two tensors on one storage: a residual
+        block hands the first to its successor's convolution and the second to its identity path, and backward receives
+        their gradients separately and sums them inside the kernel -- otherwise autograd adds them in a kernel of its own."""
 
         @staticmethod
-        def backward(ctx, gy):
+        def forward(ctx, x, identity, w, b, mean, var, eps, fork, bn2):
+            y = K.bn_act_fwd(x.contiguous(), None if identity is None else identity.contiguous(), w, b, mean, var, eps, BN_VARIANT, relu=True,
+                             bn2=bn2)
+            ctx.save_for_backward(y, w, var)
+            ctx.eps, ctx.has_identity = eps, identity is not None
+            ctx.bn2 = None if bn2 is None else (bn2[0], bn2[3], bn2[4])          # weight2, var2, eps2
+            ctx.set_materialize_grads(False)
+            return (y, y.detach()) if fork else y
+
+        @staticmethod
+        def backward(ctx, *grads):
             y, w, var = ctx.saved_tensors
-            gx, gid = K.bn_relu_bwd(gy.contiguous(), y, w, var, ctx.eps, BN_VARIANT, want_identity=ctx.has_identity)
-            return gx, gid, None, None, None, None, None
+            live = [g.contiguous() for g in grads if g is not None]
+            if not live:
+                return (None,) * 9
+            gx, gid = K.bn_relu_bwd(live[0], y, w, var, ctx.eps, BN_VARIANT, want_identity=ctx.has_identity,
+                                    gy2=live[1] if len(live) > 1 else None, bn2=ctx.bn2)
+            return gx, gid, None, None, None, None, None, None, None
     return BnReluFunction
 
 
@@ -84,56 +95,90 @@ _FN = None
 _CHECK = {"on": False, "sites": 0}
 
 
-def _eager(x, bn, identity):
+def _eager(x, bn, identity, identity_bn=None):
     import torch.nn.functional as F
     out = bn(x)
-    return F.relu(out if identity is None else out + identity)
+    if identity is not None:
+        out = out + (identity if identity_bn is None else identity_bn(identity))
+    return F.relu(out)
 
 
-def _check_site(x, bn, identity, fused_fn):
-    """Fused vs PyTorch kernels on the tensors of this call site: forward and both gradients must be bit-identical."""
+def _check_site(x, bn, identity, fused_fn, fork, identity_bn=None):
+    """Fused vs PyTorch kernels on the tensors of this call site: forward and all gradients must be bit-identical."""
     import torch
     xa, xb = x.detach().clone().requires_grad_(True), x.detach().clone().requires_grad_(True)
     ia = ib = None
     if identity is not None:
         ia, ib = identity.detach().clone().requires_grad_(True), identity.detach().clone().requires_grad_(True)
     with torch.enable_grad():
-        ya, yb = _eager(xa, bn, ia), fused_fn(xb, ib)
-        gy = torch.randn_like(ya)
-        ga = torch.autograd.grad(ya, [xa] + ([ia] if ia is not None else []), gy)
-        gb = torch.autograd.grad(yb, [xb] + ([ib] if ib is not None else []), gy)
+        ya, yb = _eager(xa, bn, ia, identity_bn), fused_fn(xb, ib)
+        g1, g2 = torch.randn_like(ya), torch.randn_like(ya)
+        if fork:                                      # the output is used twice: autograd adds the two gradients, the kernel sums them itself
+            ga = torch.autograd.grad([ya, ya], [xa] + ([ia] if ia is not None else []), [g1, g2])
+            gb = torch.autograd.grad([yb, yb._xai_alias], [xb] + ([ib] if ib is not None else []), [g1, g2])
+        else:
+            ga = torch.autograd.grad(ya, [xa] + ([ia] if ia is not None else []), g1)
+            gb = torch.autograd.grad(yb, [xb] + ([ib] if ib is not None else []), g1)
     if not (torch.equal(ya, yb) and all(torch.equal(p, q) for p, q in zip(ga, gb))):
         raise ValueError(f"fuse_bn_relu: fused BN+ReLU differs from the PyTorch kernels for input {tuple(x.shape)}"
                          f"{' + identity' if identity is not None else ''} (forward equal: {torch.equal(ya, yb)})")
     _CHECK["sites"] += 1
 
 
-def bn_relu(x, bn, identity=None):
+def _bn_usable(bn, x):
+    import torch
+    return (not bn.training and bn.track_running_stats and bn.running_mean is not None and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == 4 and not (bn.weight is not None and bn.weight.requires_grad)
+            and not (bn.bias is not None and bn.bias.requires_grad))
+
+
+def bn_relu(x, bn, identity=None, fork=False, identity_bn=None):
     """relu(bn(x) [+ identity]) through the fused kernels; falls back to the PyTorch modules whenever the fused form does
-    not apply (training mode, trainable BN parameters, no running statistics, non-fp32 or non-HIP tensors)."""
+    not apply (training mode, trainable BN parameters, no running statistics, non-fp32 or non-HIP tensors).
+    identity_bn: the identity operand is a raw convolution output and gets this BatchNorm2d inside the same kernel (the
+    down-sample branch of a residual block).
+    fork=True (block outputs): the result carries a second tensor on the same storage as `._xai_alias`; a following fused
+    block routes its identity path through it so that the two gradients of the residual join reach the backward kernel
+    separately (see BnReluFunction).  Anything else just uses the result as an ordinary tensor."""
     global _FN
     import torch
-    usable = (not bn.training and bn.track_running_stats and bn.running_mean is not None and x.is_cuda and x.dtype == torch.float32
-              and x.dim() == 4 and not (bn.weight is not None and bn.weight.requires_grad)
-              and not (bn.bias is not None and bn.bias.requires_grad) and (identity is None or identity.shape == x.shape))
+    usable = (_bn_usable(bn, x) and (identity is None or identity.shape == x.shape)
+              and (identity_bn is None or (identity is not None and _bn_usable(identity_bn, identity))))
     if not usable:
-        return _eager(x, bn, identity)
+        return _eager(x, bn, identity, identity_bn)
     if _FN is None:
         _FN = _make_function()
     w, b, mean, var = _bn_tensors(bn, x)
-    fused_fn = lambda xx, ii: _FN.apply(xx, ii, w, b, mean, var, float(bn.eps))      # noqa: E731
+    bn2 = None if identity_bn is None else (*_bn_tensors(identity_bn, x), float(identity_bn.eps))
+
+    def fused_fn(xx, ii, forked=None):
+        forked = (fork and torch.is_grad_enabled() and xx.requires_grad) if forked is None else forked
+        if not forked:
+            return _FN.apply(xx, ii, w, b, mean, var, float(bn.eps), False, bn2)
+        y, alias = _FN.apply(xx, ii, w, b, mean, var, float(bn.eps), True, bn2)
+        y._xai_alias = alias
+        return y
     if _CHECK["on"]:
-        _check_site(x, bn, identity, fused_fn)
+        _check_site(x, bn, identity, (lambda xx, ii: fused_fn(xx, ii, fork)), fork, identity_bn)
     return fused_fn(x, identity)
 
 
 def _fused_block_forward(self, x):
-    identity = x if self.downsample is None else self.downsample(x)
+    import torch.nn as nn
+    side = getattr(x, "_xai_alias", x)              # the previous fused block's second handle on its output, if any
+    identity, identity_bn = side, None
+    ds = self.downsample
+    if ds is not None:
+        if isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d) and isinstance(ds[1], nn.BatchNorm2d):
+            identity, identity_bn = ds[0](side), ds[1]          # conv here, its BatchNorm inside the residual kernel
+        else:
+            identity = ds(side)
     out = bn_relu(self.conv1(x), self.bn1)
+    fork = getattr(self, "_xai_fork", False)
     if hasattr(self, "conv3"):                      # bottleneck
         out = bn_relu(self.conv2(out), self.bn2)
-        return bn_relu(self.conv3(out), self.bn3, identity)
-    return bn_relu(self.conv2(out), self.bn2, identity)     # basic block
+        return bn_relu(self.conv3(out), self.bn3, identity, fork=fork, identity_bn=identity_bn)
+    return bn_relu(self.conv2(out), self.bn2, identity, fork=fork, identity_bn=identity_bn)     # basic block
 
 
 _POOL_FN = None
@@ -198,12 +243,18 @@ def _is_block(m):
     return all(hasattr(m, n) for n in names) and isinstance(m.bn1, nn.BatchNorm2d) and isinstance(m.relu, nn.ReLU)
 
 
-def fuse_bn_relu(model, verify=None):
+def fuse_bn_relu(model, verify=None, fork_residual=False):
     """Copy of `model` (a ResNet of torchvision's layout: stem conv1/bn1/relu/maxpool, layer1-4 of BasicBlock / Bottleneck
     modules, avgpool, fc) whose blocks run BN + ReLU (+ add) through the fused kernels.  Parameter names, buffers and hooks
     are untouched (only `forward` of the blocks and of the stem is replaced).  `verify`: an example input batch on the HIP
     device; every fused call site is then compared bitwise (forward, gradients) with the PyTorch kernels on the tensors
-    that reach it, else ValueError."""
+    that reach it, else ValueError.
+    `fork_residual=True` additionally removes autograd's gradient add at every residual join: a block output then exists as
+    two tensors on one storage (the second rides on the first as `._xai_alias` and feeds the next block's identity path),
+    and the fused backward kernel sums their gradients itself.  Values are unchanged, but the gradient with respect to an
+    inner block's output is then split over the two handles: code that takes `autograd.grad(score, hooked_activation)` on
+    such an output must add the gradient of `hooked_activation._xai_alias` (xai_engine.gradcam.LayerGradCam does); the
+    output of the last block, which no fused block consumes, is not affected.  Off by default for that reason."""
     import types
     import torch
     import torch.nn as nn
@@ -212,6 +263,7 @@ def fuse_bn_relu(model, verify=None):
     for mod in m.modules():
         if _is_block(mod) and type(mod).forward is not _fused_block_forward:
             mod.forward = types.MethodType(_fused_block_forward, mod)
+            mod._xai_fork = bool(fork_residual)
             n_blocks += 1
     stem = all(hasattr(m, n) for n in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool", "fc"))
     if stem and isinstance(m.bn1, nn.BatchNorm2d):

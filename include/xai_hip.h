@@ -213,16 +213,22 @@ int xai_causal_apply_f32(const float* x, const float* masks, const float* noise,
  * an identity).  Not a replacement of a reference expression: the reference's classifiers are torchvision modules
  * (XAI_Survey/evaluations/evaluatePerturbation.py:627-640) whose BatchNorm2d / ReLU / residual add run as separate
  * PyTorch kernels; this fuses them.   x, identity, y : [N][C][HW];  weight, bias, mean, var : [C]
- *   variant : ordering of the arithmetically equivalent BN expression (see csrc/bnrelu_kernels.hip) */
+ *   variant : ordering of the arithmetically equivalent BN expression (see csrc/bnrelu_kernels.hip)
+ *   weight2 .. eps2 (nullable as a set): the identity operand is a raw convolution output with its own eval-mode
+ *   BatchNorm (the down-sample branch): y = relu( bn(x) + bn2(identity) ) */
 int xai_bn_act_fwd_f32(const float* x, const float* identity, const float* weight, const float* bias,
-                       const float* mean, const float* var, float eps, int variant, int relu, int N, int C,
-                       int HW, float* y, xai_stream_t stream);
+                       const float* mean, const float* var, float eps, const float* weight2,
+                       const float* bias2, const float* mean2, const float* var2, float eps2, int variant,
+                       int relu, int N, int C, int HW, float* y, xai_stream_t stream);
 
 /* backward of the ReLU form, reached through the autograd.grad of saliencyMethods.py:213 (getGradientsParallel):
- * g1 = y > 0 ? gy : 0;  gx = g1 * weight * invstd;  g_identity (nullable) = g1 */
-int xai_bn_relu_bwd_f32(const float* gy, const float* y, const float* weight, const float* var, float eps,
-                        int variant, int N, int C, int HW, float* gx, float* g_identity,
-                        xai_stream_t stream);
+ * g = gy [+ gy2];  g1 = y > 0 ? g : 0;  gx = g1 * weight * invstd;  g_identity (nullable) = g1
+ *   gy2 (nullable): the second gradient of a block output that feeds both the next convolution and the next identity path
+ *   weight2, var2, eps2 (nullable as a set): g_identity = g1 * weight2 * invstd2, the gradient of the identity operand
+ *   before its own BatchNorm */
+int xai_bn_relu_bwd_f32(const float* gy, const float* gy2, const float* y, const float* weight, const float* var,
+                        float eps, const float* weight2, const float* var2, float eps2, int variant, int N,
+                        int C, int HW, float* gx, float* g_identity, xai_stream_t stream);
 
 /* MaxPool2d backward from the forward's arg-max indices (int64, h * W + w within a plane), windows added in (ph, pw)
  * ascending order like PyTorch's max_pool_backward_nchw -> bit-identical; the stem of the classifiers instantiated at

@@ -734,12 +734,23 @@ def test_fuse_bn_relu_model_sites_verified_names_and_hooks_kept():
     x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
     fused = fuse_bn_relu(model, verify=x)                      # every call site bitwise equal to the PyTorch kernels, else ValueError
     assert list(fused.state_dict()) == list(model.state_dict())
+    forked = fuse_bn_relu(model, verify=x, fork_residual=True)  # + the residual-join gradient add inside the backward kernel
+    xc = x.clone().requires_grad_(True)
+    oc = forked(xc)
+    (gc_,) = torch.autograd.grad(oc[:, 3].sum(), xc)
+    assert not hasattr(oc, "_xai_alias")
+    # Grad-CAM on an INNER layer of the forked model: the activation's gradient is split over two handles, LayerGradCam adds them
+    t_in = int(oc[0].argmax())
+    inner_a = gradcam_saliency(model, model.layer2, x[:1], t_in, (64, 64))
+    inner_b = gradcam_saliency(forked, forked.layer2, x[:1], t_in, (64, 64))
+    assert rel_inf(inner_b.cpu().numpy(), inner_a.cpu().numpy()) <= 1e-4
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     oa, ob = model(xa), fused(xb)
     (ga,), (gb,) = torch.autograd.grad(oa[:, 3].sum(), xa), torch.autograd.grad(ob[:, 3].sum(), xb)
     # whole-model: equal up to the run-to-run noise of MIOpen's convolutions (the original differs from itself by as much)
     assert rel_inf(ob.detach().cpu().numpy(), oa.detach().cpu().numpy()) <= 1e-5
     assert rel_inf(gb.cpu().numpy(), ga.cpu().numpy()) <= 1e-3
+    assert rel_inf(oc.detach().cpu().numpy(), oa.detach().cpu().numpy()) <= 1e-5 and rel_inf(gc_.cpu().numpy(), ga.cpu().numpy()) <= 1e-3
     t = int(oa[0].argmax())
     cam_a = gradcam_saliency(model, model.layer4, x[:1], t, (64, 64))
     cam_b = gradcam_saliency(fused, fused.layer4, x[:1], t, (64, 64))          # forward hook on layer4 still fires
