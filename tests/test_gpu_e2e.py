@@ -771,3 +771,55 @@ def test_fuse_bn_relu_model_sites_verified_names_and_hooks_kept():
         gy = torch.randn_like(ya)
         (ga,), (gb,) = torch.autograd.grad(ya, xa, gy), torch.autograd.grad(yb, xb, gy)
         assert torch.equal(ya, yb) and torch.equal(ga, gb), shape
+
+
+def test_fuse_bn_relu_on_a_torchvision_style_basic_block_network():
+    """torchvision's ResNet-18/34 layout (BasicBlock: two 3x3 convolutions, in-place ReLU, optional down-sample) -- written
+    out here because torchvision itself is not installed -- through fuse_bn_relu with every call site verified."""
+    import torch.nn as nn
+    from xai_engine.prepare import fuse_bn_relu
+
+    class BasicBlock(nn.Module):
+        def __init__(self, cin, cout, stride):
+            super().__init__()
+            self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False); self.bn1 = nn.BatchNorm2d(cout)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False); self.bn2 = nn.BatchNorm2d(cout)
+            self.downsample = None
+            if stride != 1 or cin != cout:
+                self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+        def forward(self, x):
+            identity = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            out += identity
+            return self.relu(out)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 8, 7, 2, 3, bias=False); self.bn1 = nn.BatchNorm2d(8); self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(3, 2, 1)
+            self.layer1 = nn.Sequential(BasicBlock(8, 8, 1), BasicBlock(8, 8, 1)); self.layer2 = nn.Sequential(BasicBlock(8, 16, 2), BasicBlock(16, 16, 1))
+            self.layer3 = nn.Sequential(BasicBlock(16, 32, 2)); self.layer4 = nn.Sequential(BasicBlock(32, 64, 2), BasicBlock(64, 64, 1))
+            self.avgpool = nn.AdaptiveAvgPool2d(1); self.fc = nn.Linear(64, 10)
+
+        def forward(self, x):
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            return self.fc(torch.flatten(self.avgpool(x), 1))
+
+    torch.manual_seed(0)
+    model = Net().to(DEV).eval()
+    _randomise_bn(model, seed=2)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(3, 3, 50, 62, generator=torch.Generator().manual_seed(9)).to(DEV)          # odd sizes: scalar kernel paths
+    for fork in (False, True):
+        fused = fuse_bn_relu(model, verify=x, fork_residual=fork)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        oa, ob = model(xa), fused(xb)
+        (ga,), (gb,) = torch.autograd.grad(oa[:, 1].sum(), xa), torch.autograd.grad(ob[:, 1].sum(), xb)
+        assert rel_inf(ob.detach().cpu().numpy(), oa.detach().cpu().numpy()) <= 1e-5
+        assert rel_inf(gb.cpu().numpy(), ga.cpu().numpy()) <= 1e-3
