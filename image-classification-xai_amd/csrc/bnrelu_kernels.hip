@@ -250,3 +250,47 @@ XAI_EXPORT int xai_maxpool_bwd_f32(const float* gy, const int64_t* indices, int 
     hipLaunchKernelGGL(maxpool_bwd_kernel<0>, grid, dim3(256), 0, st, gy, indices, H, W, PH, PW, kernel, stride, pad, gx);
   return xai_launch_status();
 }
+
+// ---- inference-only stem: max_pool( relu( bn(x) ) ) in one pass --------------------------------------------------------
+// One lane per pooled output: the (up to k x k) inputs of its window go through the BN expression and ReLU in registers and
+// only the maximum is written -- the 4x larger un-pooled activation is never stored.  Forward-only loops (RISE, the
+// insertion / deletion sequences) run the classifier without autograd, so nothing downstream needs that activation.
+// Values are those of PyTorch's three kernels (a maximum has no rounding); NaN wins like in max_pool_forward_nchw.
+namespace {
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, const float* __restrict__ mean,
+                                                              const float* __restrict__ var, float eps, int variant, int C, int H, int W,
+                                                              int PH, int PW, int k, int stride, int pad, float* __restrict__ y) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= PH * PW) return;
+  const int plane = blockIdx.y;
+  const int c = plane % C;
+  const float m = mean[c], is = inv_std(var[c], eps, variant), wc = w[c], bc = b[c];
+  const int ph = q / PW, pw = q - ph * PW;
+  const int h0 = max(ph * stride - pad, 0), h1 = min(ph * stride - pad + k, H);
+  const int w0 = max(pw * stride - pad, 0), w1 = min(pw * stride - pad + k, W);
+  const float* src = x + static_cast<int64_t>(plane) * H * W;
+  float best = -INFINITY;
+  for (int h = h0; h < h1; ++h)
+    for (int ww = w0; ww < w1; ++ww) {
+      const float v = fmaxf(bn_value(src[h * W + ww], m, is, wc, bc, variant), 0.f);
+      if (v > best || v != v) best = v;
+    }
+  y[static_cast<int64_t>(plane) * PH * PW + q] = best;
+}
+
+}  // namespace
+
+XAI_EXPORT int xai_bn_relu_maxpool_fwd_f32(const float* x, const float* weight, const float* bias, const float* mean, const float* var,
+                                           float eps, int variant, int N, int C, int H, int W, int PH, int PW, int kernel, int stride,
+                                           int pad, float* y, xai_stream_t stream) {
+  XAI_REQUIRE_PTR(x); XAI_REQUIRE_PTR(weight); XAI_REQUIRE_PTR(bias); XAI_REQUIRE_PTR(mean); XAI_REQUIRE_PTR(var); XAI_REQUIRE_PTR(y);
+  XAI_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && kernel > 0 && stride > 0 && pad >= 0 && variant >= 0 && variant < 16,
+              XAI_E_SHAPE);
+  XAI_REQUIRE(static_cast<int64_t>(N) * C <= 65535 && static_cast<int64_t>(H) * W <= INT32_MAX, XAI_E_UNSUPPORTED);
+  dim3 grid(static_cast<unsigned>(xai_ceil_div(static_cast<int64_t>(PH) * PW, 256)), N * C);
+  hipLaunchKernelGGL(bn_relu_maxpool_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, weight, bias, mean, var, eps, variant,
+                     C, H, W, PH, PW, kernel, stride, pad, y);
+  return xai_launch_status();
+}

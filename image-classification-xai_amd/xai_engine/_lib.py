@@ -48,6 +48,7 @@ SIGNATURES = {
     "xai_bn_act_fwd_f32": [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p, _p],
     "xai_bn_relu_bwd_f32": [_p, _p, _p, _p, _p, _f, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p],
     "xai_maxpool_bwd_f32": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p],
+    "xai_bn_relu_maxpool_fwd_f32": [_p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p],
 }
 _RESTYPE = {"xai_strerror": C.c_char_p, "xai_rank_workspace_bytes": C.c_size_t, "xai_gradcam_workspace_bytes": C.c_size_t}
 

@@ -407,3 +407,17 @@ def maxpool_bwd(gy, indices, H, W, kernel, stride, pad):
     gx = torch.empty((N, Cc, int(H), int(W)), dtype=F32, device=gy.device)
     _call("xai_maxpool_bwd_f32", gy.device, _ptr(gy), _ptr(indices), N * Cc, int(H), int(W), PH, PW, int(kernel), int(stride), int(pad), _ptr(gx))
     return gx
+
+
+def bn_relu_maxpool_fwd(x, weight, bias, mean, var, eps, variant, kernel, stride, pad):
+    """max_pool2d(relu(bn(x)), kernel, stride, pad) for inference; x (N,C,H,W) -> (N,C,PH,PW)."""
+    _need(x, F32, "x")
+    for name, t in (("weight", weight), ("bias", bias), ("mean", mean), ("var", var)):
+        _need(t, F32, name)
+    N, Cc, H, W = x.shape
+    PH = (H + 2 * pad - kernel) // stride + 1
+    PW = (W + 2 * pad - kernel) // stride + 1
+    y = torch.empty((N, Cc, PH, PW), dtype=F32, device=x.device)
+    _call("xai_bn_relu_maxpool_fwd_f32", x.device, _ptr(x), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(var), float(eps), int(variant),
+          N, Cc, H, W, PH, PW, int(kernel), int(stride), int(pad), _ptr(y))
+    return y

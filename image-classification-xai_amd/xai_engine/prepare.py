@@ -230,9 +230,37 @@ def max_pool(x, pool):
     return _POOL_FN.apply(x, k, s, p)
 
 
+def stem_inference(x, bn, pool):
+    """max_pool(relu(bn(x))) in one kernel when nothing needs a gradient (forward-only loops); None when it does not apply."""
+    import torch
+    import torch.nn as nn
+    from . import kernels as K
+
+    def one(v):
+        return v if isinstance(v, int) else (v[0] if v[0] == v[1] else None)
+    if torch.is_grad_enabled() and x.requires_grad:
+        return None
+    if not (isinstance(pool, nn.MaxPool2d) and _bn_usable(bn, x) and x.is_contiguous()):
+        return None
+    k, s, p, d = one(pool.kernel_size), one(pool.stride), one(pool.padding), one(pool.dilation)
+    if None in (k, s, p) or d != 1 or pool.ceil_mode or pool.return_indices or x.shape[0] * x.shape[1] > 65535 or 2 * p > k:
+        return None
+    w, b, mean, var = _bn_tensors(bn, x)
+    y = K.bn_relu_maxpool_fwd(x, w, b, mean, var, float(bn.eps), BN_VARIANT, k, s, p)
+    if _CHECK["on"]:
+        if not torch.equal(y, pool(_eager(x, bn, None))):
+            raise ValueError(f"fuse_bn_relu: the fused inference stem differs from the PyTorch kernels for input {tuple(x.shape)}")
+        _CHECK["sites"] += 1
+    return y
+
+
 def _fused_resnet_forward(self, x):
     import torch
-    x = max_pool(bn_relu(self.conv1(x), self.bn1), self.maxpool)
+    stem = self.conv1(x)
+    pooled = stem_inference(stem, self.bn1, self.maxpool)
+    if pooled is None or _CHECK["on"]:                    # (a verification pass walks both forms of the stem)
+        pooled = max_pool(bn_relu(stem, self.bn1), self.maxpool)
+    x = pooled
     x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
     return self.fc(torch.flatten(self.avgpool(x), 1))
 

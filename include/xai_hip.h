@@ -236,6 +236,13 @@ int xai_bn_relu_bwd_f32(const float* gy, const float* gy2, const float* y, const
 int xai_maxpool_bwd_f32(const float* gy, const int64_t* indices, int planes, int H, int W, int PH, int PW,
                         int kernel, int stride, int pad, float* gx, xai_stream_t stream);
 
+/* inference-only stem: y = max_pool2d( relu( bn(x) ), kernel, stride, pad ) in one pass (no autograd; the un-pooled
+ * activation is never written); same classifiers, evaluatePerturbation.py:627-640, as run by the forward-only loops of
+ * MASTestFunctions.py:273 and generate_emap.py:91-97.   x : [N][C][H*W];  y : [N][C][PH*PW] */
+int xai_bn_relu_maxpool_fwd_f32(const float* x, const float* weight, const float* bias, const float* mean,
+                                const float* var, float eps, int variant, int N, int C, int H, int W, int PH,
+                                int PW, int kernel, int stride, int pad, float* y, xai_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

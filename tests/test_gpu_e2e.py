@@ -760,6 +760,16 @@ def test_fuse_bn_relu_model_sites_verified_names_and_hooks_kept():
     assert rel_inf(ig_b.cpu().numpy(), ig_a.cpu().numpy()) <= 2e-3             # ReLU-gate flips from conv noise, as between any two runs
     with pytest.raises(ValueError):
         fuse_bn_relu(torch.nn.Sequential(torch.nn.Conv2d(3, 3, 1)).to(DEV))
+    # inference (no autograd): the stem runs as one bn+relu+max-pool kernel, bit-identical to the three PyTorch kernels
+    from xai_engine.prepare import stem_inference
+    with torch.no_grad():
+        stem = model.conv1(x)
+        one = stem_inference(stem, model.bn1, model.maxpool)
+        assert one is not None and torch.equal(one, model.maxpool(torch.relu(model.bn1(stem))))
+        odd = torch.randn(2, 16, 37, 53, device=DEV)
+        assert torch.equal(stem_inference(odd, model.bn1, model.maxpool), model.maxpool(torch.relu(model.bn1(odd))))
+        assert rel_inf(fused(x).cpu().numpy(), model(x).cpu().numpy()) <= 1e-5
+    assert stem_inference(stem.clone().requires_grad_(True), model.bn1, model.maxpool) is None      # autograd needs the full activation
     # the stem's max-pool backward: bit-identical to PyTorch's, also for odd sizes and other geometries
     from xai_engine.prepare import max_pool
     for shape, (k, s_, p) in (((3, 5, 112, 112), (3, 2, 1)), ((2, 4, 31, 45), (3, 2, 1)), ((2, 3, 20, 20), (2, 2, 0)), ((1, 2, 17, 9), (3, 1, 1))):
