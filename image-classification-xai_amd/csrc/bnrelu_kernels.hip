@@ -280,6 +280,59 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
   y[static_cast<int64_t>(plane) * PH * PW + q] = best;
 }
 
+// Tiled form: a workgroup owns kPoolRows pooled rows of one plane; the input rows they cover are read once, coalesced, put
+// through BN + ReLU and parked in LDS (out-of-range positions as -inf), then every lane takes the maximum of its window
+// from LDS.  The direct form above reads each input up to (k/stride)^2 times with a stride-2 lane pattern and ran at
+// 1.6 TB/s on the benchmark's stem (803 MB for 250 images).
+constexpr int kPoolRows = 8;
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ b, const float* __restrict__ mean,
+                                                                    const float* __restrict__ var, float eps, int variant, int C, int H,
+                                                                    int W, int PH, int PW, int k, int stride, int pad,
+                                                                    float* __restrict__ y) {
+  extern __shared__ float tile[];                       // [rows][W + 2 * pad]
+  const int plane = blockIdx.y;
+  const int c = plane % C;
+  const float m = mean[c], is = inv_std(var[c], eps, variant), wc = w[c], bc = b[c];
+  const int ph0 = blockIdx.x * kPoolRows;
+  const int n_out = min(kPoolRows, PH - ph0);
+  const int rows = (n_out - 1) * stride + k;
+  const int h_first = ph0 * stride - pad;               // input row of tile row 0 (may be negative)
+  const int TWp = W + 2 * pad;
+  const float* src = x + static_cast<int64_t>(plane) * H * W;
+  // 8 loads in flight per lane before the first LDS store (a store between two loads serialises them on the HBM latency)
+  for (int base = threadIdx.x; base < rows * TWp; base += 256 * 8) {
+    float v[8];
+    bool in[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256;
+      const int r = i / TWp, cx = i - r * TWp;
+      const int h = h_first + r, ww = cx - pad;
+      in[u] = i < rows * TWp && h >= 0 && h < H && ww >= 0 && ww < W;
+      v[u] = in[u] ? src[h * W + ww] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256;
+      if (i < rows * TWp) tile[i] = in[u] ? fmaxf(bn_value(v[u], m, is, wc, bc, variant), 0.f) : -INFINITY;
+    }
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < n_out * PW; q += 256) {
+    const int pr = q / PW, pw = q - pr * PW;
+    const float* t = tile + (pr * stride) * TWp + pw * stride;
+    float best = -INFINITY;
+    for (int a = 0; a < k; ++a)
+      for (int bb = 0; bb < k; ++bb) {
+        const float v = t[a * TWp + bb];
+        if (v > best || v != v) best = v;
+      }
+    y[(static_cast<int64_t>(plane) * PH + ph0 + pr) * PW + pw] = best;
+  }
+}
+
 }  // namespace
 
 XAI_EXPORT int xai_bn_relu_maxpool_fwd_f32(const float* x, const float* weight, const float* bias, const float* mean, const float* var,
@@ -289,8 +342,15 @@ XAI_EXPORT int xai_bn_relu_maxpool_fwd_f32(const float* x, const float* weight, 
   XAI_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && kernel > 0 && stride > 0 && pad >= 0 && variant >= 0 && variant < 16,
               XAI_E_SHAPE);
   XAI_REQUIRE(static_cast<int64_t>(N) * C <= 65535 && static_cast<int64_t>(H) * W <= INT32_MAX, XAI_E_UNSUPPORTED);
-  dim3 grid(static_cast<unsigned>(xai_ceil_div(static_cast<int64_t>(PH) * PW, 256)), N * C);
-  hipLaunchKernelGGL(bn_relu_maxpool_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, weight, bias, mean, var, eps, variant,
-                     C, H, W, PH, PW, kernel, stride, pad, y);
+  const size_t lds = static_cast<size_t>((kPoolRows - 1) * stride + kernel) * (W + 2 * pad) * sizeof(float);
+  if (lds <= 48 * 1024) {
+    dim3 grid(static_cast<unsigned>(xai_ceil_div(PH, kPoolRows)), N * C);
+    hipLaunchKernelGGL(bn_relu_maxpool_tiled_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, weight, bias, mean, var, eps,
+                       variant, C, H, W, PH, PW, kernel, stride, pad, y);
+  } else {
+    dim3 grid(static_cast<unsigned>(xai_ceil_div(static_cast<int64_t>(PH) * PW, 256)), N * C);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, weight, bias, mean, var, eps, variant,
+                       C, H, W, PH, PW, kernel, stride, pad, y);
+  }
   return xai_launch_status();
 }
