@@ -26,6 +26,9 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
+    # rehearsal knobs (same as bench.py's): XAI_DIST_BACKEND=gloo + XAI_FORCE_DEVICE=0 let several ranks share one GPU
+    backend = backend or os.environ.get("XAI_DIST_BACKEND")
+    local = int(os.environ.get("XAI_FORCE_DEVICE", local))
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
