@@ -103,6 +103,23 @@ def run(device="cuda:0", verbose=True):
     stack = K.causal_apply(img, m, noise, 0.1)
     add = (noise * 0.1) * (1 - m.view(4, 1, 64, 64))
     check("causal_apply", _rel(stack, torch.cat([img[None] * m.view(4, 1, 64, 64) + add, img[None] + add])), 0.0)
+    # opt-in classifier fusion: must reproduce THIS PyTorch build's eval-mode BN / ReLU / max-pool kernels bit for bit
+    from .prepare import BN_VARIANT
+    xb_, idt_, gy_ = rnd(3, 8, 14, 14), rnd(3, 8, 14, 14), rnd(3, 8, 14, 14)
+    wv, bv, mv, vv = rnd(8).abs() + 0.5, rnd(8), rnd(8), rnd(8).abs() + 0.2
+    xr, ir = xb_.clone().requires_grad_(True), idt_.clone().requires_grad_(True)
+    yv = F.relu(F.batch_norm(xr, mv, vv, wv, bv, False, 0.0, 1e-5) + ir)
+    yv.backward(gy_)
+    check("bn_act_fwd (bitwise vs PyTorch)", float((K.bn_act_fwd(xb_, idt_, wv, bv, mv, vv, 1e-5, BN_VARIANT) != yv.detach()).sum()), 0.0)
+    gx, gid = K.bn_relu_bwd(gy_, yv.detach(), wv, vv, 1e-5, BN_VARIANT, want_identity=True)
+    check("bn_relu_bwd (bitwise vs PyTorch)", float((gx != xr.grad).sum() + (gid != ir.grad).sum()), 0.0)
+    xp = rnd(2, 4, 15, 17).requires_grad_(True)
+    yp, ip = F.max_pool2d(xp, 3, 2, 1, 1, False, True)
+    gp = rnd(*yp.shape)
+    yp.backward(gp)
+    check("maxpool_bwd (bitwise vs PyTorch)", float((K.maxpool_bwd(gp, ip, 15, 17, 3, 2, 1) != xp.grad).sum()), 0.0)
+    want = F.max_pool2d(F.relu(F.batch_norm(xb_, mv, vv, wv, bv, False, 0.0, 1e-5)), 3, 2, 1)
+    check("bn_relu_maxpool_fwd (bitwise vs PyTorch)", float((K.bn_relu_maxpool_fwd(xb_, wv, bv, mv, vv, 1e-5, BN_VARIANT, 3, 2, 1) != want).sum()), 0.0)
     return all(r[3] for r in results), results
 
 
