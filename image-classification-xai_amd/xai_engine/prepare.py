@@ -39,6 +39,17 @@ def use_tuned_miopen_db(rank=0, src=None):
     src = src or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "miopen_db")
     if not os.path.isdir(src) or not os.listdir(src):
         return False
+    # the files are named <arch><cus>.HIP.<major>_<minor>_<patch>_...: MIOpen ignores a db of another version, and find mode
+    # without a db means minutes of search on first use -- stay in immediate mode then
+    import re
+    import torch
+    try:
+        v = int(torch.backends.cudnn.version() or 0)
+    except Exception:
+        v = 0
+    want = f"{v // 1000000}_{(v // 1000) % 1000}_{v % 1000}_"
+    if not any(re.search(r"\.HIP\." + re.escape(want), f) for f in os.listdir(src)):
+        return False
     dst = os.path.join(tempfile.gettempdir(), f"xai_miopen_db_{os.getuid()}_{rank}")
     try:
         shutil.rmtree(dst, ignore_errors=True)
