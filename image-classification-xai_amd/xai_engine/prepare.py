@@ -197,7 +197,7 @@ _POOL_FN = None
 
 def max_pool(x, pool):
     """pool(x) with PyTorch's forward (and its arg-max indices) and the fused library's backward (same accumulation order as
-    PyTorch's max_pool_backward_nchw, a quarter of its time); anything but a plain square MaxPool2d takes the module."""
+    PyTorch's max_pool_backward_nchw, half its time); anything but a plain square MaxPool2d takes the module."""
     global _POOL_FN
     import torch
     import torch.nn as nn
@@ -284,8 +284,10 @@ def _is_block(m):
 
 def fuse_bn_relu(model, verify=None, fork_residual=False):
     """Copy of `model` (a ResNet of torchvision's layout: stem conv1/bn1/relu/maxpool, layer1-4 of BasicBlock / Bottleneck
-    modules, avgpool, fc) whose blocks run BN + ReLU (+ add) through the fused kernels.  Parameter names, buffers and hooks
-    are untouched (only `forward` of the blocks and of the stem is replaced).  `verify`: an example input batch on the HIP
+    modules, avgpool, fc) whose blocks run BN + ReLU (+ add) through the fused kernels.  Parameter names and buffers are
+    untouched (only `forward` of the blocks and of the stem is replaced); hooks on the network, its layers, blocks and
+    convolutions fire as before, hooks on the BatchNorm2d / ReLU / down-sample container modules INSIDE a fused block do
+    not (those modules are no longer called, their parameters are read directly).  `verify`: an example input batch on the HIP
     device; every fused call site is then compared bitwise (forward, gradients) with the PyTorch kernels on the tensors
     that reach it, else ValueError.
     `fork_residual=True` additionally removes autograd's gradient add at every residual join: a block output then exists as
