@@ -833,3 +833,23 @@ def test_fuse_bn_relu_on_a_torchvision_style_basic_block_network():
         (ga,), (gb,) = torch.autograd.grad(oa[:, 1].sum(), xa), torch.autograd.grad(ob[:, 1].sum(), xb)
         assert rel_inf(ob.detach().cpu().numpy(), oa.detach().cpu().numpy()) <= 1e-5
         assert rel_inf(gb.cpu().numpy(), ga.cpu().numpy()) <= 1e-3
+
+
+def test_cli_runs_resnet50_with_the_fused_classifier(tmp_path):
+    """python -m xai_engine.evaluate_perturbation on a directory of three synthetic files, ResNet-50 (seeded random weights),
+    Grad-CAM, --fuse_bn_relu: the selection pre-pass and the sweep run through the fused classifier; a CSV (when the
+    reference's sanity filter lets a random-weight prediction through at all) has the reference's twelve rows."""
+    from PIL import Image
+    from xai_engine import evaluate_perturbation as cli
+    root = tmp_path / "val"
+    root.mkdir()
+    rng = np.random.default_rng(11)
+    for i in range(1, 4):
+        blocks = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+        Image.fromarray(np.kron(blocks, np.ones((32, 32, 1), dtype=np.uint8))).save(root / f"ILSVRC2012_val_{i:08d}.JPEG", format="PNG")
+    out = tmp_path / "res"
+    cli.main(["--model", "R50", "--attr_func", "gc", "--image_count", "2", "--dataset_path", str(root), "--fuse_bn_relu",
+              "--out_dir", str(out)])
+    for f in (out / "R50").glob("gc_*_images.csv"):
+        rows = f.read_text().strip().splitlines()
+        assert len(rows) == 12 and rows[0].startswith("MAS_ins,") and rows[-2].startswith("Attr Avg Runtime,")
