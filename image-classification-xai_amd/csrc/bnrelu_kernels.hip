@@ -14,6 +14,14 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// every activation / gradient tensor here is read exactly once by these kernels: non-temporal loads keep them from pushing
+// the just-written outputs (which the next convolution reads at once) out of L2 / Infinity Cache
+typedef float fx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  const fx4 v = __builtin_nontemporal_load(reinterpret_cast<const fx4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float inv_std(float var, float eps, int variant) {
   return (variant & 1) ? rsqrtf(var + eps) : 1.f / sqrtf(var + eps);
 }
@@ -64,11 +72,11 @@ __global__ __launch_bounds__(kBlock) void bn_act_fwd_kernel(const float* __restr
   float m2 = 0.f, is2 = 1.f, w2 = 1.f, b2 = 0.f;
   if (second) { m2 = bn2.mean[c]; is2 = inv_std(bn2.var[c], bn2.eps, variant); w2 = bn2.w[c]; b2 = bn2.b[c]; }
   if (VEC) {
-    const float4 v = ld4(x + i);
+    const float4 v = ld4_nt(x + i);
     float4 o = make_float4(bn_value(v.x, m, is, wc, bc, variant), bn_value(v.y, m, is, wc, bc, variant),
                            bn_value(v.z, m, is, wc, bc, variant), bn_value(v.w, m, is, wc, bc, variant));
     if (ADD) {
-      float4 a = ld4(idt + i);
+      float4 a = ld4_nt(idt + i);
       if (second)
         a = make_float4(bn_value(a.x, m2, is2, w2, b2, variant), bn_value(a.y, m2, is2, w2, b2, variant),
                         bn_value(a.z, m2, is2, w2, b2, variant), bn_value(a.w, m2, is2, w2, b2, variant));
@@ -100,12 +108,12 @@ __global__ __launch_bounds__(kBlock) void bn_relu_bwd_kernel(const float* __rest
   float is2 = 1.f, w2 = 1.f;
   if (second) { is2 = inv_std(bn2.var[c], bn2.eps, variant); w2 = bn2.w[c]; }
   if (VEC) {
-    float4 g = ld4(gy + i);
+    float4 g = ld4_nt(gy + i);
     if (gy2 != nullptr) {
-      const float4 h = ld4(gy2 + i);
+      const float4 h = ld4_nt(gy2 + i);
       g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
     }
-    const float4 o = ld4(y + i);
+    const float4 o = ld4_nt(y + i);
     const float4 g1 = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
     st4(gx + i, make_float4(bn_grad(g1.x, is, wc, variant), bn_grad(g1.y, is, wc, variant), bn_grad(g1.z, is, wc, variant),
                             bn_grad(g1.w, is, wc, variant)));
