@@ -376,6 +376,14 @@ def test_abi_argument_errors(K):
     assert lib.xai_ig_interp_f32(x.data_ptr(), None, 0.0, x.data_ptr(), 0, 0, 1, 4, x.data_ptr(), None) == -2
     assert lib.xai_gradcam_f32(x.data_ptr(), x.data_ptr(), 1, 1, 64, 64, 1, x.data_ptr(), None, 0, None) == -3
     assert lib.xai_blur_sep_f32(x.data_ptr(), x.data_ptr(), 4, 1, 1, 2, 2, x.data_ptr(), None) == -2
+    p = x.data_ptr()
+    assert lib.xai_bn_act_fwd_f32(p, None, p, p, p, None, 1e-5, None, None, None, None, 0.0, 9, 1, 1, 2, 4, p, None) == -1     # var missing
+    assert lib.xai_bn_act_fwd_f32(p, None, p, p, p, p, 1e-5, None, None, None, None, 0.0, 99, 1, 1, 2, 4, p, None) == -2     # variant
+    assert lib.xai_bn_act_fwd_f32(p, p, p, p, p, p, 1e-5, None, None, None, None, 0.0, 9, 0, 1, 2, 4, p, None) == -3         # identity needs relu
+    assert lib.xai_bn_act_fwd_f32(p, None, p, p, p, p, 1e-5, p, p, p, p, 1e-5, 9, 1, 1, 2, 4, p, None) == -1                 # bn2 needs identity
+    assert lib.xai_bn_relu_bwd_f32(p, None, p, p, p, 1e-5, p, p, 1e-5, 9, 1, 2, 4, p, None, None) == -1                     # bn2 needs g_identity
+    assert lib.xai_maxpool_bwd_f32(p, p, 1, 2, 2, 1, 1, 0, 2, 0, p, None) == -2                                             # kernel 0
+    assert lib.xai_bn_relu_maxpool_fwd_f32(p, p, p, p, p, 1e-5, 9, 70000, 1, 2, 2, 1, 1, 2, 2, 0, p, None) == -3           # > 65535 planes
 
 
 # ------------------------------------------------------------------------------ f4 accumulators on K2's weighted form
