@@ -1,0 +1,124 @@
+"""Randomised shapes (seeded) for the element-wise / index kernels against the CPU oracle: the fixed-shape tests pin the
+BASELINE sizes, these walk odd widths, non-multiples of 4, single rows, batch tails.  Integer / byte / element-wise
+results exact, fp32 reductions <= 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_inf
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def K():
+    from xai_engine import kernels, load_library
+    load_library()
+    return kernels
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype is not None else t).to(DEV).contiguous()
+
+
+def shapes(seed, n):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        yield int(rng.integers(1, 5)), int(rng.integers(1, 70)), int(rng.integers(1, 90)), rng
+
+
+def test_interp_and_accumulate_random_shapes(K):
+    from oracle import ig as oig
+    for C, H, W, rng in shapes(1, 12):
+        S = int(rng.integers(1, 23))
+        x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+        b = rng.standard_normal((1, C, H, W)).astype(np.float32)
+        al = np.sort(rng.random(S)).astype(np.float32)
+        got = K.ig_interp(dev(x), dev(b), dev(al))[0].cpu().numpy()
+        assert np.array_equal(got, np.asarray(oig.interpolate(x, b, al)).reshape(got.shape)), (C, H, W, S)   # separate multiply and add: bit-exact
+        g = rng.standard_normal((1, S, C, H, W)).astype(np.float32)
+        n_use = int(rng.integers(1, S + 1))
+        nu = torch.tensor([n_use], dtype=torch.int32, device=DEV)
+        out, out_abs = K.ig_accum(dev(g), dev(x), dev(b), n_use=nu, want_abs=True)
+        want = oig.accumulate(g[0], n_use, x[0], b[0])
+        assert rel_inf(out[0].cpu().numpy(), want) <= 1e-5, (C, H, W, S, n_use)
+        assert rel_inf(out_abs[0].cpu().numpy(), np.abs(want.sum(0))) <= 1e-5
+
+
+def test_rank_flip_perturb_segment_random_shapes(K):
+    from oracle import perturb as op
+    for C, H, W, rng in shapes(2, 12):
+        hw = H * W
+        sal = rng.standard_normal(hw).astype(np.float32)
+        sal[rng.integers(0, hw, max(1, hw // 5))] = 0.0                                      # ties
+        order, rank = K.rank(dev(sal[None]))
+        want_order = np.argsort(sal, kind="stable")
+        assert np.array_equal(order[0].cpu().numpy(), want_order)
+        assert np.array_equal(rank[0].cpu().numpy()[want_order], np.arange(hw))
+        step = int(rng.integers(1, hw + 1))
+        n_steps = -(-hw // step)
+        for desc in (True, False):
+            flip = K.flip_steps(rank[0], desc, step)
+            pos = (hw - 1 - rank[0].cpu().numpy()) if desc else rank[0].cpu().numpy()
+            assert np.array_equal(flip.cpu().numpy(), pos // step)
+            start = rng.standard_normal((C, H, W)).astype(np.float32)
+            finish = rng.standard_normal((C, H, W)).astype(np.float32)
+            first = int(rng.integers(0, n_steps))
+            nb = int(rng.integers(1, n_steps - first + 1))
+            imgs = K.perturb_batch(dev(start), dev(finish), flip, first, nb).cpu().numpy()
+            f = (pos // step).reshape(1, H, W)
+            for k in range(nb):
+                assert np.array_equal(imgs[k], np.where(f <= first + k, finish, start)), (C, H, W, step, desc, k)
+            seg, total = K.segment_sums(dev(sal), order[0], desc, step, n_steps)
+            seq = want_order[::-1] if desc else want_order
+            want_seg = np.array([sal[seq[t * step:(t + 1) * step]].astype(np.float64).sum() for t in range(n_steps)])
+            assert np.abs(seg.cpu().numpy() - want_seg).max() <= 1e-5 * max(np.abs(want_seg).max(), 1e-6) + 1e-6
+            assert abs(float(total) - sal.astype(np.float64).sum()) <= 1e-4 * max(abs(sal.astype(np.float64)).sum(), 1.0)
+
+
+def test_softmax_stats_and_blur_random_shapes(K):
+    from oracle import perturb as op
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        B, Kc = int(rng.integers(1, 60)), int(rng.integers(2, 1200))
+        z = (rng.standard_normal((B, Kc)) * rng.uniform(0.5, 6)).astype(np.float32)
+        t = int(rng.integers(0, Kc))
+        p, ent, am = K.softmax_stats(dev(z), t)
+        sm = op.softmax_rows(z)
+        assert rel_inf(p.cpu().numpy(), sm[:, t]) <= 1e-5
+        assert rel_inf(ent.cpu().numpy(), op.entropy_bits(sm)) <= 1e-4
+        assert np.array_equal(am.cpu().numpy(), z.argmax(1))
+    for C, H, W, rng in shapes(4, 8):
+        klen = int(rng.choice([3, 5, 11, 31, 63]))
+        k1 = op.gkern1d(klen, max(1.0, klen / 2)).astype(np.float32)
+        x = rng.standard_normal((2, C, H, W)).astype(np.float32)
+        got = K.blur_sep(dev(x), dev(k1)).cpu().numpy()
+        kern = torch.zeros(C, C, klen, klen)
+        for c in range(C):
+            kern[c, c] = torch.outer(torch.from_numpy(k1), torch.from_numpy(k1))
+        want = torch.nn.functional.conv2d(torch.from_numpy(x).double(), kern.double(), padding=klen // 2).numpy()
+        assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), (C, H, W, klen)
+
+
+def test_gradcam_bilinear_and_maskers_random_shapes(K):
+    from oracle import gradcam as ogc
+    from oracle import vit_cx as ocx
+    rng = np.random.default_rng(5)
+    for _ in range(8):
+        B, Cc, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 300)), int(rng.integers(1, 15)), int(rng.integers(1, 15))
+        act = rng.standard_normal((B, Cc, h, w)).astype(np.float32)
+        grad = rng.standard_normal((B, Cc, h, w)).astype(np.float32)
+        cam = K.gradcam(dev(act), dev(grad), relu=True)
+        want = ogc.cam_reduce(act, grad, relu=True)
+        assert np.abs(cam.cpu().numpy() - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3)
+        Ho, Wo = int(rng.integers(h, 8 * h + 2)), int(rng.integers(w, 8 * w + 2))
+        up = K.bilinear_up(cam, Ho, Wo).cpu().numpy()
+        assert np.abs(up - ogc.bilinear_up(cam.cpu().numpy(), Ho, Wo)).max() <= 2e-6 * max(np.abs(want).max(), 1e-3)
+        if h * w >= 2:
+            fm = rng.standard_normal((Cc, h, w)).astype(np.float32)
+            rows = K.up_rownorm(dev(fm), Ho, Wo).cpu().numpy()
+            ref = ocx.norm_matrix(ocx.resize_maps(fm, Ho, Wo).reshape(Cc, Ho * Wo))
+            ok = np.isfinite(ref).all(axis=1)                                                  # constant maps are 0/0 in both
+            assert np.abs(rows[ok] - ref[ok]).max(initial=0.0) <= 4e-6
