@@ -122,3 +122,28 @@ def test_gradcam_bilinear_and_maskers_random_shapes(K):
             ref = ocx.norm_matrix(ocx.resize_maps(fm, Ho, Wo).reshape(Cc, Ho * Wo))
             ok = np.isfinite(ref).all(axis=1)                                                  # constant maps are 0/0 in both
             assert np.abs(rows[ok] - ref[ok]).max(initial=0.0) <= 4e-6
+
+
+def test_rise_random_geometries(K):
+    """RISE masks and accumulation for random image sizes, grid sizes s (the bit-packed s = 8 path and the generic one),
+    keep probabilities and mask counts, against the oracle's scipy up-sampling."""
+    from oracle import rise as orise
+    rng0 = np.random.default_rng(8)
+    for _ in range(10):
+        H, W = int(rng0.integers(9, 120)), int(rng0.integers(9, 120))
+        s = int(rng0.choice([2, 3, 5, 7, 8, 8, 11]))
+        N = int(rng0.integers(1, 40))
+        p1 = float(rng0.uniform(0.2, 0.8))
+        rng = np.random.RandomState(int(rng0.integers(0, 1 << 30)))
+        grid, shifts, cell = orise.draw_grid_and_shifts((H, W), N, s, p1, rng)
+        image = rng0.standard_normal((3, H, W)).astype(np.float32)
+        g8, sh = dev(grid.astype(np.uint8)), dev(shifts)
+        masked, masks = K.rise_apply(g8, sh, cell, dev(image), want_masked=True, want_masks=True)
+        want_masks = orise.masks_from(grid, shifts, (H, W), cell)[:, 0]
+        assert np.abs(masks.cpu().numpy() - want_masks).max() <= 1e-6, (H, W, s, N)
+        assert masks.min() >= 0 and masks.max() <= 1
+        np.testing.assert_array_equal(masked.cpu().numpy(), image[None] * masks.cpu().numpy()[:, None])
+        scores = rng0.random(N).astype(np.float32)
+        acc = K.rise_accum(g8, sh, dev(scores), cell, H, W, 1.0 / N / p1)
+        want = (scores.reshape(-1, 1).astype(np.float64) * want_masks.reshape(N, -1)).sum(0).reshape(H, W) / N / p1
+        assert np.abs(acc.cpu().numpy() - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-3), (H, W, s, N)
