@@ -239,6 +239,62 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   gx[static_cast<int64_t>(blockIdx.y) * H * W + p] = g;
 }
 
+// Tiled form of the same gather: a workgroup owns kBwdRows input rows of one plane; the pooled rows whose windows can
+// reach them (indices truncated to int32, and gradients) are staged in LDS with coalesced loads, 8 in flight per lane, and
+// every lane then walks its (at most NW x NW) candidate windows in LDS in the same (ph, pw) order.
+constexpr int kBwdRows = 16;
+
+template <int NW>
+__global__ __launch_bounds__(256) void maxpool_bwd_tiled_kernel(const float* __restrict__ gy, const int64_t* __restrict__ idx, int H, int W,
+                                                                int PH, int PW, int k, int stride, int pad, float* __restrict__ gx) {
+  extern __shared__ int lds_i[];                         // [rows][PW] indices, then [rows][PW] gradients
+  const int h0 = blockIdx.x * kBwdRows;
+  const int h_last = min(h0 + kBwdRows, H) - 1;
+  const int pr0 = (h0 + pad < k) ? 0 : (h0 + pad - k) / stride + 1;           // first pooled row that can cover row h0
+  const int pr1 = min((h_last + pad) / stride + 1, PH);                         // one past the last that can cover h_last
+  const int rows = pr1 - pr0;
+  float* lds_g = reinterpret_cast<float*>(lds_i + rows * PW);
+  const int64_t off = static_cast<int64_t>(blockIdx.y) * PH * PW + static_cast<int64_t>(pr0) * PW;
+  const int total = rows * PW;
+  for (int base = threadIdx.x; base < total; base += 256 * 8) {
+    int iv[8];
+    float gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256;
+      iv[u] = i < total ? static_cast<int>(idx[off + i]) : -1;
+      gv[u] = i < total ? gy[off + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256;
+      if (i < total) { lds_i[i] = iv[u]; lds_g[i] = gv[u]; }
+    }
+  }
+  __syncthreads();
+  const int n_rows = h_last - h0 + 1;
+  for (int q = threadIdx.x; q < n_rows * W; q += 256) {
+    const int r = q / W, w = q - r * W;
+    const int h = h0 + r, p = h * W + w;
+    const int ph0 = (h + pad < k) ? 0 : (h + pad - k) / stride + 1;
+    const int ph1 = min((h + pad) / stride + 1, PH);
+    const int pw0 = (w + pad < k) ? 0 : (w + pad - k) / stride + 1;
+    const int pw1 = min((w + pad) / stride + 1, PW);
+    float g = 0.f;
+#pragma unroll
+    for (int a = 0; a < NW; ++a)
+#pragma unroll
+      for (int b = 0; b < NW; ++b) {
+        const int ph = ph0 + a, pw = pw0 + b;
+        if (ph < ph1 && pw < pw1) {
+          const int t = (ph - pr0) * PW + pw;
+          if (lds_i[t] == p) g += lds_g[t];
+        }
+      }
+    gx[static_cast<int64_t>(blockIdx.y) * H * W + p] = g;
+  }
+}
+
 }  // namespace
 
 XAI_EXPORT int xai_maxpool_bwd_f32(const float* gy, const int64_t* indices, int planes, int H, int W, int PH, int PW, int kernel,
@@ -250,6 +306,16 @@ XAI_EXPORT int xai_maxpool_bwd_f32(const float* gy, const int64_t* indices, int 
   dim3 grid(static_cast<unsigned>(xai_ceil_div(static_cast<int64_t>(H) * W, 256)), planes);
   const int nw = (kernel + stride - 1) / stride;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int pooled_rows = (kBwdRows + kernel - 2) / stride + 2;                   // upper bound of the pooled rows one tile needs
+  const size_t lds = static_cast<size_t>(pooled_rows) * PW * 8;
+  if (nw <= 2 && lds <= 48 * 1024) {
+    dim3 tgrid(static_cast<unsigned>(xai_ceil_div(H, kBwdRows)), planes);
+    if (nw == 1)
+      hipLaunchKernelGGL(maxpool_bwd_tiled_kernel<1>, tgrid, dim3(256), lds, st, gy, indices, H, W, PH, PW, kernel, stride, pad, gx);
+    else
+      hipLaunchKernelGGL(maxpool_bwd_tiled_kernel<2>, tgrid, dim3(256), lds, st, gy, indices, H, W, PH, PW, kernel, stride, pad, gx);
+    return xai_launch_status();
+  }
   if (nw == 1)
     hipLaunchKernelGGL(maxpool_bwd_kernel<1>, grid, dim3(256), 0, st, gy, indices, H, W, PH, PW, kernel, stride, pad, gx);
   else if (nw == 2)
