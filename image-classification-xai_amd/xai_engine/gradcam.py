@@ -115,9 +115,9 @@ class CapturedGradCam:
 
     def _verify(self, model, layer, channels):
         """Replay against the eager path on the example input for two classes.  A graph is only as good as every node in
-        it: captured hipMemsetAsync nodes have been observed not to take effect on replay in ROCm 7.2 (see
-        csrc/rank_kernels.hip), and a classifier kernel that relies on one (zero-fill + atomics) would replay wrong --
-        profiles/experiments/exp_captured_ig.py shows exactly that for a whole captured IG attribution."""
+        it, and most of these nodes are library kernels we do not control: a whole captured IG attribution
+        (profiles/experiments/exp_captured_ig.py) did NOT reproduce its eager result on one of the two networks tried, for
+        a reason that was not isolated -- so a captured Grad-CAM proves itself on this model before it is handed out."""
         x = self.x.detach().clone()
         n_cls = int(_n_classes(model, x))
         for t in {0, n_cls - 1}:
