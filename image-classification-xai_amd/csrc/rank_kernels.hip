@@ -60,8 +60,9 @@ __device__ __forceinline__ SegPtrs seg_ptrs(uint32_t* ws, int seg, int n_seg, in
 }
 
 // zero the front of the scratch (flags + histograms).  A kernel rather than hipMemsetAsync: captured through
-// torch.cuda.graph the library's memset did not take effect on replay (tests/test_gpu_kernels.py graph test); a stand-alone
-// captured memset node (tune/repro_graph_memset.hip) does replay, so the cause is not isolated -- the kernel is simply safe.
+// torch.cuda.graph the library's memset once appeared not to take effect on replay (tests/test_gpu_kernels.py graph test);
+// a stand-alone captured memset node (tune/repro_graph_memset.hip) does replay, so that observation is not trusted -- the
+// kernel costs the same and is kept.
 __global__ __launch_bounds__(kBlock) void rank_zero_kernel(uint32_t* __restrict__ w, size_t n_words) {
   const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
   for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_words; i += stride) w[i] = 0u;

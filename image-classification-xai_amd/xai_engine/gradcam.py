@@ -114,10 +114,10 @@ class CapturedGradCam:
             self._verify(model, layer, channels)
 
     def _verify(self, model, layer, channels):
-        """Replay against the eager path on the example input for two classes.  A graph is only as good as every node in
-        it, and most of these nodes are library kernels we do not control: a whole captured IG attribution
-        (profiles/experiments/exp_captured_ig.py) did NOT reproduce its eager result on one of the two networks tried, for
-        a reason that was not isolated -- so a captured Grad-CAM proves itself on this model before it is handed out."""
+        """Replay against the eager path on the example input for two classes.  A graph replays raw pointers: every tensor
+        its kernels read (inputs, targets, parameters, anything allocated outside the capture) has to outlive it, and most
+        of its nodes are library kernels we do not control -- so a captured Grad-CAM proves itself on this model before it is
+        handed out."""
         x = self.x.detach().clone()
         n_cls = int(_n_classes(model, x))
         for t in {0, n_cls - 1}:

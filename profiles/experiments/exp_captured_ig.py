@@ -1,5 +1,6 @@
-"""Does a hipGraph replay of a whole IG attribution reproduce the eager result?  (On ResNet-50 it differs by what MIOpen's
-algorithm choice under capture plus ReLU-gate flips explain; on the tiny test network it was erratic, cause not isolated.)"""
+"""The whole one-image IG attribution (K1, classifier forward / backward, filing, K2) as one hipGraph replay: does it
+reproduce the eager result, and is it faster?  (Every tensor the captured kernels read must outlive the graph -- a first
+version of this script let the `alphas` tensor go out of scope after capture and "found" replays that were off by 2 %.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "image-classification-xai_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,10 +15,10 @@ class CapturedIG:
     def __init__(self, model, example_input, steps, batch_size):
         self.dev, self.x, self.base = _prep(example_input.detach().clone(), 0, example_input.device)
         self.target = torch.zeros((), dtype=torch.int64, device=self.dev)
-        alphas = torch.linspace(0, 1, steps).to(self.dev)
+        self.alphas = torch.linspace(0, 1, steps).to(self.dev)          # read by the captured K1: must live as long as the graph
 
         def run():
-            grads, logits = _path(self.x, self.base, alphas, model, batch_size, self.target)
+            grads, logits = _path(self.x, self.base, self.alphas, model, batch_size, self.target)
             return K.ig_accum(grads, self.x, self.base)[0]
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
