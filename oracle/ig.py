@@ -173,3 +173,22 @@ def idgi(x, model, steps, batch_size, baseline, target):
         sq = grads[i] * grads[i]
         acc += sq * (logits[i + 1] - logits[i]) / sq.sum(dtype=F32)
     return acc
+
+
+def smoothgrad_ig(x, model, steps, baseline, target, sigma_spread=.15, samples=25):
+    """smoothGrad("IG", ..., vis=True) [saliencyMethods.py:184-205] -> (mean, total_gradients, noisy_imgs).
+    Noise: one torch.normal per sample from the GLOBAL CPU generator (the very call the reference makes, :191 -- seed it
+    with torch.manual_seed before calling), std = sigma_spread * (max - min) as a float32 0-d tensor.  IG runs with
+    batch_size = int(steps / 2) (:196).  The tuple-unpacking of :196 keeps only channel 0 of every sample and
+    broadcasts it over the channels."""
+    xt = torch.from_numpy(np.asarray(x, dtype=F32))
+    stdev = sigma_spread * (torch.max(xt) - torch.min(xt))
+    total = np.zeros((samples,) + xt.shape[1:], dtype=F32)
+    noisy = np.zeros((samples,) + xt.shape[1:], dtype=F32)
+    for i in range(samples):
+        noise = torch.normal(mean=0, std=stdev, size=xt.shape)
+        noisy[i] = (xt + noise).numpy()[0]
+        a = ig(noisy[i][None], model, steps, int(steps / 2), 1, baseline, target)
+        total[i] = a[0][None]                       # first of the three unpacked (H,W) slices, broadcast
+    mean = total.sum(axis=0, dtype=F32) / F32(samples)
+    return mean, total, noisy

@@ -25,6 +25,7 @@ What is pinned (reference file:line in brackets):
   vit_cx.npz                  ViT-CX norm_matrix / cosine similarity / token reshape and causal_score.forward
                               [ViT_CX/ViT_CX.py:22-46, ViT_CX/causal_score.py:17-61]
   tis.npz                     TIS on the mini ViT, every stage except the absent k-means [TIS.py:96-365]
+  smoothgrad.npz              seeded smoothGrad("IG", ..., vis=True): mean, total_gradients, noisy_imgs [saliencyMethods.py:184-205]
   sweep_small.npz             the 10-key Counter of run_perturbation, driven exactly like
                               XAI_Survey/evaluations/evaluatePerturbation.py:448-497
 The only stubs are inert placeholder modules: `cvxopt` (used by the reference only under
@@ -467,10 +468,38 @@ def tis_fixture():
     print("tis.npz", {k: v.shape for k, v in out.items()})
 
 
+def smoothgrad_fixture():
+    """Seeded reference smoothGrad on the tiny net of ig_small.npz [saliencyMethods.py:184-205]: the noise comes from the
+    global CPU generator in the reference and in the build alike, so `torch.manual_seed` pins the draw.  vis=True returns
+    (mean, total_gradients, noisy_imgs); "IG" is the branch the harness uses (evaluatePerturbation.py:118)."""
+    g = np.load(os.path.join(HERE, "ig_small.npz"))
+    model = tiny_model(100)
+    assert all(np.array_equal(v, g[k]) for k, v in weights_of(model).items())
+    x = torch.from_numpy(g["x"])
+    target = torch.tensor(int(g["target"]))
+    out = {}
+    for tag, steps, samples, spread, base in (("a", 10, 3, .15, 0), ("b", 20, 4, .3, 0.1)):
+        torch.manual_seed(77)
+        mean, total, noisy = attr.smoothGrad("IG", x.clone(), model, steps, base, target, "cpu", sigma_spread=spread, samples=samples, vis=True)
+        torch.manual_seed(77)
+        only = attr.smoothGrad("IG", x.clone(), model, steps, base, target, "cpu", sigma_spread=spread, samples=samples)
+        assert torch.equal(only, mean)
+        out.update({f"{tag}_steps": np.int64(steps), f"{tag}_samples": np.int64(samples), f"{tag}_sigma_spread": np.float64(spread),
+                    f"{tag}_baseline": np.float64(base), f"{tag}_mean": mean.detach().numpy(), f"{tag}_total_gradients": total.detach().numpy(),
+                    f"{tag}_noisy_imgs": noisy.detach().numpy()})
+    out["seed"] = np.int64(77)
+    np.savez(os.path.join(HERE, "smoothgrad.npz"), **out)
+    print("smoothgrad.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 KEYS = ["MAS_ins", "MAS_del", "RISE_ins", "RISE_del", "AIC_ins", "AIC_del", "LERF_res", "MORF_res", "MONO_pos", "MONO_neg"]
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                                   # python make_golden.py smoothgrad_fixture [...]: only those
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        raise SystemExit
     ig_fixture("ig_small.npz", 32, 100)
     ig_fixture("ig_224.npz", 224, 200)
     kern_fixture()
@@ -482,3 +511,4 @@ if __name__ == "__main__":
     cam_fixture()
     vitcx_fixture()
     tis_fixture()
+    smoothgrad_fixture()

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_inf
+from conftest import load_golden, rel_inf, check
 from helpers import tiny_from, logits_fn_of, vit_mini_from
 
 
@@ -54,8 +54,8 @@ def test_IG_signature_and_parity(attr, name):
         got = got.cpu().numpy()
         base_np = base.numpy() if torch.is_tensor(base) else base
         want = oig.ig(g["x"], model, steps, bs, a_star, base_np, int(target))           # (a) same device model
-        assert rel_inf(got, want) <= 1e-5, (key, rel_inf(got, want))
-        assert rel_inf(got, g[key]) <= 2e-3, (key, rel_inf(got, g[key]))                  # (b) reference on CPU
+        check(f"IG/{name}/{key}", got, want, 1e-5, "oracle")
+        check(f"IG/{name}/{key}", got, g[key], 2e-3)                                      # (b) reference on CPU
     assert attr.IG(x, model, 50, 7, 1, 0, DEV, target) == (0, 0, 0, 0)                  # quirk kept
 
 
@@ -83,18 +83,19 @@ def test_IDG_IDGI_and_helpers(attr):
     t = torch.tensor(int(g["target"]))
     slopes, step = attr.getSlopes(torch.zeros_like(x), x.clone(), model, 50, 25, DEV, t)
     assert step == float(g["slope_step"])
-    assert rel_inf(slopes.cpu().numpy(), g["slopes"]) <= 1e-3
+    check("getSlopes/ig_small", slopes.cpu().numpy(), g["slopes"], 1e-3)
     al, sub = attr.getAlphaParameters(torch.from_numpy(g["slopes"]), 50, float(g["slope_step"]))
     np.testing.assert_array_equal(al.numpy(), g["idg_alphas"])
     np.testing.assert_array_equal(sub.numpy(), g["idg_substep"])
     idgi = attr.IDGI(x.clone(), model, 50, 25, 0, DEV, t).cpu().numpy()
-    assert rel_inf(idgi, oig.idgi(g["x"], model, 50, 25, 0, int(t))) <= 1e-4
-    assert rel_inf(idgi, g["idgi"]) <= 1e-3
+    check("IDGI/ig_small", idgi, oig.idgi(g["x"], model, 50, 25, 0, int(t)), 1e-4, "oracle")
+    check("IDGI/ig_small", idgi, g["idgi"], 1e-3)
     idg = attr.IDG(x.clone(), model, 50, 25, 0, DEV, t).cpu().numpy()
-    assert rel_inf(idg, g["idg"]) <= 5e-3            # slope weights are differences of near-equal logits
+    check("IDG/ig_small", idg, oig.idg(g["x"], model, 50, 25, 0, int(t)), 1e-4, "oracle")
+    check("IDG/ig_small", idg, g["idg"], 5e-3)            # slope weights are differences of near-equal logits
     xg = x.clone().to(DEV)
     ig_ = attr.input_grad(xg, model, t)
-    assert rel_inf(ig_.cpu().numpy(), g["input_grad"]) <= 1e-5
+    check("input_grad/ig_small", ig_.cpu().numpy(), g["input_grad"], 1e-5)
 
 
 def test_smoothGrad_quirk(attr):
@@ -112,6 +113,32 @@ def test_smoothGrad_quirk(attr):
     from util.attribution_methods.saliencyMethods import IG
     want0 = torch.stack([IG(noisy[i:i + 1], model, 10, 5, 1, 0, DEV, int(g["target"]))[0] for i in range(3)]).double().mean(0)
     assert rel_inf(sg[0].cpu().numpy(), want0.cpu().numpy()) <= 2e-6
+
+
+def test_smoothGrad_vs_the_seeded_reference_run(attr):
+    """tests/golden/smoothgrad.npz = the reference's smoothGrad("IG", ..., vis=True) on the CPU under torch.manual_seed(77);
+    both implementations draw the noise from the global CPU generator, so the noisy images must be bit-equal."""
+    from oracle import ig as oig
+    g, gi = load_golden("smoothgrad.npz"), load_golden("ig_small.npz")
+    model = tiny_from(gi, DEV)
+    x = torch.from_numpy(gi["x"])
+    t = torch.tensor(int(gi["target"]))
+    for tag in ("a", "b"):
+        steps, samples = int(g[f"{tag}_steps"]), int(g[f"{tag}_samples"])
+        spread, base = float(g[f"{tag}_sigma_spread"]), float(g[f"{tag}_baseline"])
+        torch.manual_seed(int(g["seed"]))
+        mean, total, noisy = attr.smoothGrad("IG", x.clone().to(DEV), model, steps, base, t, DEV, sigma_spread=spread, samples=samples, vis=True)
+        np.testing.assert_array_equal(noisy.cpu().numpy(), g[f"{tag}_noisy_imgs"])
+        torch.manual_seed(int(g["seed"]))
+        o_mean, o_total, o_noisy = oig.smoothgrad_ig(gi["x"], model, steps, base, int(t), sigma_spread=spread, samples=samples)
+        np.testing.assert_array_equal(o_noisy, g[f"{tag}_noisy_imgs"])
+        check(f"smoothGrad/{tag}/total_gradients", total.cpu().numpy(), o_total, 1e-5, "oracle")
+        check(f"smoothGrad/{tag}/mean", mean.cpu().numpy(), o_mean, 1e-5, "oracle")
+        check(f"smoothGrad/{tag}/total_gradients", total.cpu().numpy(), g[f"{tag}_total_gradients"], 2e-3)
+        check(f"smoothGrad/{tag}/mean", mean.cpu().numpy(), g[f"{tag}_mean"], 2e-3)
+        torch.manual_seed(int(g["seed"]))
+        only = attr.smoothGrad("IG", x.clone(), model, steps, base, t, DEV, sigma_spread=spread, samples=samples)       # CPU input, vis=False
+        np.testing.assert_array_equal(only.cpu().numpy(), mean.cpu().numpy())
 
 
 # ------------------------------------------------------------------------------ ins/del metrics
@@ -157,8 +184,8 @@ def test_single_run_return_tuples(fixture):
             if np.ndim(w) == 0 and not isinstance(w, float) and ofunc != "mono":
                 assert int(r) == int(w) == int(gold), (tag, i)
                 continue
-            assert rel_inf(r, w) <= 1e-5, (tag, i, rel_inf(r, w))                 # (a) oracle on the same device model
-            assert rel_inf(r, gold) <= 1e-4, (tag, i, rel_inf(r, gold))           # (b) reference on the CPU
+            check(f"single_run/{fixture}/{tag}/ret{i}", r, w, 1e-5, "oracle")        # (a) oracle on the same device model
+            check(f"single_run/{fixture}/{tag}/ret{i}", r, gold, 1e-4)               # (b) reference on the CPU
     if pm is None:
         AIC = importlib.import_module("util.test_methods.AICTestFunctions")
         score, resp = AIC.AICMetric(model, HW, "del", int(g["step"]), torch.zeros_like).single_run(
@@ -174,12 +201,12 @@ def test_device_blur_substrate_and_mode_asserts():
     model = tiny_from(g, DEV)
     x = torch.from_numpy(g["x"])
     blur = GaussianBlur(31, 31, DEV)
-    assert rel_inf(blur(x).cpu().numpy(), g["substrate_blur"]) <= 1e-5
+    check("GaussianBlur/perturb_224", blur(x).cpu().numpy(), g["substrate_blur"], 1e-5)
     m = MAS.MASMetric(model, 224 * 224, "ins", 224, substrate_fn=blur)
     n, corrected, ent, dens, norm = m.single_run(x.clone(), g["saliency"], DEV, max_batch_size=50)
     assert n == 225
     for i, r in enumerate((n, corrected, ent, dens, norm)):
-        assert rel_inf(r, g[f"MAS_ins_ret{i}"]) <= 1e-4
+        check(f"single_run_device_blur/perturb_224/MAS_ins/ret{i}", r, g[f"MAS_ins_ret{i}"], 1e-4)
     with pytest.raises(AssertionError):
         MAS.MASMetric(model, 224 * 224, "insert", 224, substrate_fn=blur)
     assert abs(MAS.auc(np.linspace(0, 1, 225)) - 0.5) < 1e-15
@@ -193,11 +220,12 @@ def test_model_utils_and_gradcam_call_shape():
     model = tiny_from(g, DEV)
     x = torch.from_numpy(g["x"])
     pct, logit = model_utils.getPrediction(x, model, DEV, -1)
-    assert abs(float(pct) - float(g["pred_pct"])) <= 1e-5 and abs(float(logit) - float(g["pred_logit"])) <= 1e-4
+    check("model_utils.getPrediction/pct", float(pct), float(g["pred_pct"]), 1e-5)
+    check("model_utils.getPrediction/logit", float(logit), float(g["pred_logit"]), 1e-5)
     assert int(model_utils.getClass(x, model, DEV)) == int(g["pred_class"])
     assert int(model_utils.getClass(x, model, DEV, 2)) == int(g["pred_class_k2"])
     gr = model_utils.getGradients(x.clone(), model, DEV, int(g["target"]))
-    assert rel_inf(gr.cpu().numpy(), g["input_grad"]) <= 1e-5
+    check("model_utils.getGradients", gr.cpu().numpy(), g["input_grad"], 1e-5)
     # Grad-CAM through captum's call shape on the conv layer of the tiny net
     xd = x.to(DEV)
     gc = LayerGradCam(model, model.conv).attribute(xd, torch.tensor(int(g["target"])), relu_attributions=True)
@@ -226,8 +254,8 @@ def test_run_perturbation_and_fused_sweep_match_reference_counters():
         b = fused.run(x, sal)
         ref = dict(zip(KEYS, g[f"counter_{i}"]))
         for k in KEYS:
-            assert abs(a[k] - b[k]) <= 1e-6, (k, a[k], b[k])              # dedupe changes nothing
-            assert abs(a[k] - ref[k]) <= 1e-4, (k, a[k], ref[k])          # vs the reference on the CPU
+            check(f"fused_vs_8_runs/sweep_small/{i}/{k}", b[k], a[k], 1e-6, "8-run flow", absolute=True)   # dedupe changes nothing
+            check(f"run_perturbation/sweep_small/{i}/{k}", a[k], ref[k], 1e-4, absolute=True)              # vs the reference on the CPU
 
 
 class _WithLayer4(torch.nn.Module):
@@ -257,7 +285,7 @@ def test_get_CNN_attr_dispatch():
     for name, w in want.items():
         got = get_CNN_attr(x.clone(), None, t, dict(td, attr_func=name))
         assert got.shape == (32, 32) and got.dtype == np.float32
-        assert rel_inf(got, w) <= tol[name], (name, rel_inf(got, w))
+        check(f"get_CNN_attr/{name}", got, w, tol[name])
     got = get_CNN_attr(x.clone(), None, t, dict(td, attr_func="gc"))
     act, grad = ogc.layer_act_and_grad(model, model.layer4, x.to(DEV), int(t))
     assert rel_inf(got, ogc.gradcam_saliency(act, grad, 32, 32)[0]) <= 1e-5
@@ -279,7 +307,7 @@ def test_sweep_images_single_rank_and_csv(tmp_path):
     total, used, attr_t = sweep_images(images, model, DEV, lambda x, t: sal_of[next(calls)], img_hw=32, batch_size=50)
     assert used == 3
     for j, k in enumerate(KEYS):
-        assert abs(total[k] - sum(g[f"counter_{i}"][j] for i in range(3))) <= 3e-4, k
+        check(f"sweep_images/sum3/{k}", total[k], sum(g[f"counter_{i}"][j] for i in range(3)), 3e-4, absolute=True)
     path = tmp_path / "pert_test_results" / "T" / "ig_3_images.csv"
     write_csv(str(path), total, used, attr_t, 1.0)
     rows = [r.split(",") for r in open(path).read().strip().splitlines()]
@@ -298,26 +326,28 @@ def test_vit_pixel_ig_and_attention_ig(attr):
     x = torch.from_numpy(g["x"])
     t = torch.tensor(int(g["target"]))
     got = attr.IG(x.clone(), model, 50, 25, 1, 0, DEV, t).cpu().numpy()
-    assert rel_inf(got, oig.ig(g["x"], model, 50, 25, 1, 0, int(t))) <= 1e-5
-    assert rel_inf(got, g["ig"]) <= 1e-4                       # smooth network (GELU/softmax): no gate flips
+    check("vit_mini/pixel_ig", got, oig.ig(g["x"], model, 50, 25, 1, 0, int(t)), 1e-5, "oracle")
+    check("vit_mini/pixel_ig", got, g["ig"], 1e-4)             # smooth network (GELU/softmax): no gate flips
     b = Baselines(model)
     a = b.IG(x.clone(), t, steps=20, device=DEV).cpu().numpy()
     assert a.shape == (1, 4, 4)
-    assert rel_inf(a, ovit.attention_ig(model, g["x"], int(t), 20)) <= 1e-5
-    assert rel_inf(a, g["attn_ig"]) <= 1e-4
-    assert rel_inf(b.generate_raw_attn(x, DEV).cpu().numpy(), g["raw_attn"]) <= 1e-4
-    assert rel_inf(b.generate_grad(x.clone(), t, DEV).cpu().numpy(), g["attn_grad"]) <= 1e-4
+    check("vit_mini/attn_ig", a, ovit.attention_ig(model, g["x"], int(t), 20), 1e-5, "oracle")
+    check("vit_mini/attn_ig", a, g["attn_ig"], 1e-4)
+    check("vit_mini/raw_attn", b.generate_raw_attn(x, DEV).cpu().numpy(), g["raw_attn"], 1e-4)
+    check("vit_mini/attn_grad", b.generate_grad(x.clone(), t, DEV).cpu().numpy(), g["attn_grad"], 1e-4)
     xd = x.to(DEV)
-    assert rel_inf(b.generate_naive_rollout(xd)[0].cpu().numpy(), g["naive_rollout"]) <= 1e-4
-    assert rel_inf(b.generate_rollout(xd)[0].cpu().numpy(), g["rollout"]) <= 1e-4
+    check("vit_mini/naive_rollout", b.generate_naive_rollout(xd)[0].cpu().numpy(), g["naive_rollout"], 1e-4)
+    check("vit_mini/rollout", b.generate_rollout(xd)[0].cpu().numpy(), g["rollout"], 1e-4)
     st, w, fin, last_attn, last_grad = b.generate_transition_attention_maps(x.clone(), t, steps=20, device=DEV)
     for got, key in ((st, "tam_states"), (w, "tam_w"), (fin, "tam_final"), (last_attn, "tam_last_attn"), (last_grad, "tam_last_grad")):
-        assert got.shape == g[key].shape and rel_inf(got.detach().cpu().numpy(), g[key]) <= 1e-4, key
+        assert got.shape == g[key].shape
+        check(f"vit_mini/{key}", got.detach().cpu().numpy(), g[key], 1e-4)
     np.testing.assert_array_equal(w.cpu().numpy(), a)                    # T-Attn's integrated weights are Baselines.IG's map
-    assert rel_inf(b.attn_attr(x.clone(), t, device=DEV).cpu().numpy(), g["attn_attr"]) <= 1e-4
+    check("vit_mini/attn_attr", b.attn_attr(x.clone(), t, device=DEV).cpu().numpy(), g["attn_attr"], 1e-4)
     bi, bi_R = b.bidirectional(x.clone(), t, steps=20, start_layer=1, device=DEV)
-    assert rel_inf(bi.cpu().numpy(), g["bi_attr"]) <= 1e-4 and rel_inf(bi_R.cpu().numpy(), g["bi_R"]) <= 1e-4
-    assert rel_inf(b.bidirectional(x.clone(), t, steps=20, start_layer=1, mae=True, device=DEV).cpu().numpy(), g["bi_mae"]) <= 1e-4
+    check("vit_mini/bi_attr", bi.cpu().numpy(), g["bi_attr"], 1e-4)
+    check("vit_mini/bi_R", bi_R.cpu().numpy(), g["bi_R"], 1e-4)
+    check("vit_mini/bi_mae", b.bidirectional(x.clone(), t, steps=20, start_layer=1, mae=True, device=DEV).cpu().numpy(), g["bi_mae"], 1e-4)
 
 
 def test_evaluate_perturbation_on_a_directory(tmp_path):
@@ -497,7 +527,7 @@ def test_get_VIT_attr_dispatch():
         if name in key:                        # bi_attn's default start_layer=4 exceeds the mini model's depth: shape check only
             want = torch.nn.functional.interpolate(torch.from_numpy(g[key[name]])[None], size=(32, 32), mode="bilinear",
                                                    align_corners=False, antialias=True)[0, 0].abs().numpy()
-            assert rel_inf(got, want) <= 1e-4, (name, rel_inf(got, want))
+            check(f"get_VIT_attr/{name}", got, want, 1e-4)
     with pytest.raises(SystemExit):
         get_VIT_attr(x, None, t, dict(td, attr_func="nope"))
 
@@ -565,12 +595,13 @@ def test_causal_score_matches_reference_vectors():
     torch.manual_seed(505)                                            # the seed the reference ran with: same host noise draw
     scorer = causal_score(soft, (32, 32), gpu_batch=4, device=DEV)
     sal_all = scorer(x, masks, g["class_p"])
-    assert sal_all.shape == (10, 32, 32) and rel_inf(sal_all.cpu().numpy(), g["sal"]) <= 1e-5
+    assert sal_all.shape == (10, 32, 32)
+    check("causal_score/all_classes", sal_all.cpu().numpy(), g["sal"], 1e-5)
     torch.manual_seed(505)
     row = scorer(x, masks, g["class_p"], target_category=2)
-    assert rel_inf(row.cpu().numpy(), g["sal"][2]) <= 1e-5
+    check("causal_score/class2", row.cpu().numpy(), g["sal"][2], 1e-5)
     row = scorer(x, masks, g["class_p"], target_category=7, noise=torch.from_numpy(g["noise"]))
-    assert rel_inf(row.cpu().numpy(), g["sal"][7]) <= 1e-5
+    check("causal_score/class7_given_noise", row.cpu().numpy(), g["sal"][7], 1e-5)
 
 
 def test_ViT_CX_end_to_end_vs_oracle():
@@ -618,14 +649,15 @@ def test_TIS_stages_and_end_to_end():
         raw = torch.from_numpy(g[f"{tag}_raw"]).to(DEV)
         tis = TIS(model, n_masks=8, batch_size=bs, tokens_ratio=ratio, normalise=False, raw_masks=raw)
         pred, acts = tis.get_encoder_activations(x)
-        assert int(pred) == int(g[f"{tag}_pred"]) and rel_inf(acts.cpu().numpy(), g[f"{tag}_acts"]) <= 1e-5
+        assert int(pred) == int(g[f"{tag}_pred"])
+        check(f"TIS/{tag}/acts", acts.cpu().numpy(), g[f"{tag}_acts"], 1e-5)
         masks, idx = tis.generate_binary_masks(raw)
         assert np.array_equal(masks.cpu().numpy(), g[f"{tag}_masks"])
         scores = tis.generate_scores(x, int(pred), idx)
-        assert rel_inf(scores.cpu().numpy(), g[f"{tag}_scores"]) <= 1e-5
-        assert rel_inf(tis(x).cpu().numpy(), g[f"{tag}_sal"]) <= 1e-5                  # class_idx=None -> predicted class
+        check(f"TIS/{tag}/scores", scores.cpu().numpy(), g[f"{tag}_scores"], 1e-5)
+        check(f"TIS/{tag}/sal", tis(x).cpu().numpy(), g[f"{tag}_sal"], 1e-5)             # class_idx=None -> predicted class
         tis.normalise = True
-        assert rel_inf(tis(x, class_idx=int(pred)).cpu().numpy(), g[f"{tag}_sal_norm"]) <= 2e-5
+        check(f"TIS/{tag}/sal_norm", tis(x, class_idx=int(pred)).cpu().numpy(), g[f"{tag}_sal_norm"], 2e-5)
         if tag == "a":
             assert np.array_equal(idx[0].cpu().numpy(), g["a_idx"])
             assert np.array_equal(tis.mask_input(x, idx[0][:3], baseline="zero").cpu().numpy(), g["a_masked_zero"])

@@ -55,6 +55,20 @@ def test_left_cutoff_rules():
     assert oig.left_cutoff(np.array([-1.0, -2.0], dtype=np.float32), 0.9) == 1    # max<=0: -1 > -0.9 false, -2 false -> none -> 1
 
 
+def test_smoothgrad_against_the_seeded_reference_run():
+    """tests/golden/smoothgrad.npz: the reference's smoothGrad("IG", ..., vis=True) under torch.manual_seed(77)."""
+    g, gi = load_golden("smoothgrad.npz"), load_golden("ig_small.npz")
+    model = tiny_from(gi)
+    for tag in ("a", "b"):
+        torch.manual_seed(int(g["seed"]))
+        mean, total, noisy = oig.smoothgrad_ig(gi["x"], model, int(g[f"{tag}_steps"]), float(g[f"{tag}_baseline"]), int(gi["target"]),
+                                               sigma_spread=float(g[f"{tag}_sigma_spread"]), samples=int(g[f"{tag}_samples"]))
+        np.testing.assert_array_equal(noisy, g[f"{tag}_noisy_imgs"])                   # same generator, same draw, same add
+        assert rel_inf(total, g[f"{tag}_total_gradients"]) <= TOL
+        assert rel_inf(mean, g[f"{tag}_mean"]) <= TOL
+        assert np.array_equal(total[:, 0], total[:, 1]) and np.array_equal(total[:, 0], total[:, 2])     # the :196 quirk
+
+
 def test_idg_family():
     g = load_golden("ig_small.npz")
     model = tiny_from(g)
