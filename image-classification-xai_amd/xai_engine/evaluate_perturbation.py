@@ -66,7 +66,8 @@ def main(argv=None):
         model = fuse_bn_relu(model, verify=torch.randn(2, 3, 224, 224, device=device), fork_residual=True)
     testing_dict = {"models": [model, model], "imagenet_dataset": args.dataset_path, "normalize": norm, "img_hw": 224,
                     "batch_size": batch_size, "attr_func": args.attr_func, "model_name": args.model,
-                    "image_count": args.image_count, "device": str(device), "class_map_path": args.class_map}
+                    "image_count": args.image_count, "device": str(device), "class_map_path": args.class_map,
+                    "weights_path": args.weights or ""}
     total, used, _ = harness.evaluate_perturbation(testing_dict, rank=rank, world=world, fused=not args.eight_runs, out_dir=args.out_dir,
                                                      checkpoint=args.checkpoint)
     if rank == 0:

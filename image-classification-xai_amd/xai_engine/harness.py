@@ -122,9 +122,12 @@ def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pe
     def attr_fn(x, target):
         return (_sweep.get_VIT_attr if is_vit else _sweep.get_CNN_attr)(x, None, target, testing_dict)
 
+    identity = _sweep.sweep_identity(attr_func=testing_dict["attr_func"], model_name=testing_dict["model_name"],
+                                     image_count=testing_dict["image_count"], files="|".join(c[0] for c in chosen),
+                                     weights=testing_dict.get("weights_path", ""))
     total, used, attr_time = _sweep.sweep_images([c[1] for c in chosen], model, dev, attr_fn, img_hw=testing_dict["img_hw"],
                                                  batch_size=testing_dict["batch_size"], fused=fused, rank=rank, world=world,
-                                                 testing_dict=testing_dict, checkpoint=checkpoint)
+                                                 testing_dict=testing_dict, checkpoint=checkpoint, identity=identity)
     if rank == 0 and used:
         name = f'{testing_dict["attr_func"]}_{testing_dict["image_count"]}_images.csv'
         _sweep.write_csv(os.path.join(out_dir, testing_dict["model_name"], name), total, used, attr_time, time.time() - t_start)

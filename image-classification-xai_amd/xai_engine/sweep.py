@@ -253,13 +253,39 @@ def reduce_counters(local_sum, n_local, device=None, group=None, world=None):
     return Counter({k: float(vec[i]) for i, k in enumerate(KEYS)}), int(round(float(vec[-1])))
 
 
+def sweep_identity(**facts):
+    """Stable string describing WHAT a checkpointed sweep computes (attribution method, model, weights, flow, image
+    list ...): the facts as sorted `key=value` pairs, long values hashed.  A checkpoint resumes only under the same string."""
+    import hashlib
+
+    def short(v):
+        v = str(v)
+        return v if len(v) <= 40 else "sha256:" + hashlib.sha256(v.encode()).hexdigest()[:24]
+    return ";".join(f"{k}={short(facts[k])}" for k in sorted(facts))
+
+
+def model_fingerprint(model, max_tensors=8):
+    """Cheap fingerprint of a classifier's weights: class name, parameter count and the sums of its first and last
+    few tensors (enough to tell two checkpoints of one architecture apart without hashing 100 MB)."""
+    tensors = list(model.state_dict().items())
+    picked = tensors[:max_tensors // 2] + tensors[-(max_tensors // 2):]
+    parts = [type(model).__name__, str(sum(int(t.numel()) for _, t in tensors))]
+    parts += [f"{k}:{float(t.double().sum()):.10e}" for k, t in picked]
+    return "|".join(parts)
+
+
+class CheckpointMismatch(RuntimeError):
+    pass
+
+
 class SweepState:
     """Per-rank running sums of a sharded sweep, checkpointed so that a crash does not lose the run (the
     reference writes its CSV once at the very end, evaluatePerturbation.py:612).  One small JSON file per
-    rank, replaced atomically; it is only valid for the same (n_items, rank, world) split."""
+    rank, replaced atomically.  It is only valid for the same (n_items, rank, world) split AND the same
+    `identity` (see sweep_identity): resuming somebody else's sums into this run's CSV is refused loudly."""
 
-    def __init__(self, n_items, rank, world):
-        self.n_items, self.rank, self.world = n_items, rank, world
+    def __init__(self, n_items, rank, world, identity=""):
+        self.n_items, self.rank, self.world, self.identity = n_items, rank, world, identity
         self.sums = {k: 0.0 for k in KEYS}
         self.used = 0            # images folded into `sums`
         self.next_pos = 0        # position in this rank's shard list
@@ -274,38 +300,49 @@ class SweepState:
         path = self.path_for(prefix, self.rank, self.world)
         tmp = path + ".tmp"
         with open(tmp, "w") as f:
-            json.dump(dict(n_items=self.n_items, rank=self.rank, world=self.world, sums=self.sums, used=self.used,
-                           next_pos=self.next_pos, attr_time=self.attr_time), f)
+            json.dump(dict(n_items=self.n_items, rank=self.rank, world=self.world, identity=self.identity, sums=self.sums,
+                           used=self.used, next_pos=self.next_pos, attr_time=self.attr_time), f)
         os.replace(tmp, path)
 
     @classmethod
-    def load_or_new(cls, prefix, n_items, rank, world):
+    def load_or_new(cls, prefix, n_items, rank, world, identity=""):
         import json
-        st = cls(n_items, rank, world)
+        st = cls(n_items, rank, world, identity)
         path = cls.path_for(prefix, rank, world) if prefix else None
         if path and os.path.exists(path):
             d = json.load(open(path))
-            if (d.get("n_items"), d.get("rank"), d.get("world")) == (n_items, rank, world) and set(d.get("sums", {})) == set(KEYS):
-                st.sums = {k: float(d["sums"][k]) for k in KEYS}
-                st.used, st.next_pos, st.attr_time = int(d["used"]), int(d["next_pos"]), float(d["attr_time"])
+            split = (d.get("n_items"), d.get("rank"), d.get("world"))
+            if split != (n_items, rank, world) or d.get("identity", "") != identity or set(d.get("sums", {})) != set(KEYS):
+                raise CheckpointMismatch(
+                    f"{path} belongs to a different sweep and is not resumed: it holds (n_items, rank, world) = {split}, "
+                    f"identity '{d.get('identity', '')}'; this run is {(n_items, rank, world)}, identity '{identity}'. "
+                    "Use another --checkpoint prefix or delete the file.")
+            st.sums = {k: float(d["sums"][k]) for k in KEYS}
+            st.used, st.next_pos, st.attr_time = int(d["used"]), int(d["next_pos"]), float(d["attr_time"])
         return st
 
 
 def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fused=True, rank=0, world=1, testing_dict=None,
-                 checkpoint=None, checkpoint_every=25):
+                 checkpoint=None, checkpoint_every=25, identity=None):
     """Attribution + ten perturbation numbers for every image this rank owns; returns the
     globally reduced (Counter of sums, images used, seconds in attribution).
     images: sequence of (1,C,H,W) CPU/device tensors (already selected -- the order-dependent
     filters of evaluatePerturbation.py:520-576 must run as a deterministic pre-pass so that the
     1-GPU and N-GPU runs see the same list).  attr_fn(x, target) -> (H,W) float32 numpy map.
     `checkpoint`: path prefix; every `checkpoint_every` images the rank's running sums are saved and an
-    interrupted sweep with the same split resumes after the last saved image."""
+    interrupted sweep with the same split and the same `identity` resumes after the last saved image; a checkpoint
+    of another split or identity raises CheckpointMismatch.  `identity`: string from `sweep_identity(...)` naming
+    what the caller's attr_fn / image list are (the harness passes attr_func, model name, file-name hash, ...); the
+    flow (fused / eight runs), geometry and a fingerprint of the classifier's weights are always added here."""
     dev = hip_device(device)
     sweep = PerturbationSweep(model, img_hw, dev, batch_size=batch_size) if fused else None
     td = testing_dict or {"models": [model], "img_hw": img_hw, "batch_size": batch_size, "device": str(dev)}
     blur = GaussianBlur(31, 31, dev)
     mine = shard_indices(len(images), rank, world)
-    st = SweepState.load_or_new(checkpoint, len(images), rank, world)
+    ident = ""
+    if checkpoint:
+        ident = sweep_identity(caller=identity or "", fused=fused, img_hw=img_hw, batch_size=batch_size, model=model_fingerprint(model))
+    st = SweepState.load_or_new(checkpoint, len(images), rank, world, ident)
 
     def fold(c, pos):
         for k in KEYS:                                   # plain sums: see DESIGN.md on the reference's Counter `+=`
@@ -316,6 +353,7 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
             st.save(checkpoint)
 
     pending = None                                       # (handle, pos) of the image whose device work is in flight
+    failed = None
     try:
         for pos in range(st.next_pos, len(mine)):
             x = images[mine[pos]]
@@ -337,9 +375,17 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
                 pending = (handle, pos)
             else:
                 fold(run_perturbation(x.cpu(), sal, td, blur=blur), pos)
+    except BaseException as e:
+        failed = e
+        raise
     finally:
         if pending is not None:                          # also on an exception: the queued image is complete work, keep it
-            fold(sweep.finish(pending[0]), pending[1])
+            try:
+                fold(sweep.finish(pending[0]), pending[1])
+            except Exception:
+                if failed is None:                       # nothing else went wrong: this IS the error
+                    raise
+                # a device error already in flight makes the fold fail too: the original exception is the one to report
     return (*reduce_counters(st.sums, st.used, dev, world=world), st.attr_time)
 
 

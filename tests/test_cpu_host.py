@@ -188,10 +188,17 @@ for j, k in enumerate(sweep.KEYS):
 lo, hi = xd.mask_range(8001, rank, world)
 sizes = torch.tensor([hi - lo]); dist.all_reduce(sizes); assert int(sizes) == 8001
 rng = np.random.RandomState(100 + rank)
-masks = ((rng.rand(6, 8, 8) < 0.5).astype(np.uint8), rng.randint(0, 28, (6, 2)).astype(np.int32), np.array([28, 28]))
+masks = ((rng.rand(6, 8, 8) < 0.5).astype(np.uint8), rng.randint(0, 28, (6, 2)).astype(np.int32), np.array([28 + rank, 28]))
+calls = []
+real = dist.broadcast
+dist.broadcast = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
 g, s, c = xd.broadcast_masks(masks, device)
+dist.broadcast = real
+assert len(calls) == 1                                          # ONE packed broadcast, not one per array
 r0 = np.random.RandomState(100)
 np.testing.assert_array_equal(g, (r0.rand(6, 8, 8) < 0.5).astype(np.uint8))
+np.testing.assert_array_equal(s, r0.randint(0, 28, (6, 2)).astype(np.int32))
+assert g.dtype == np.uint8 and s.dtype == np.int32 and c.tolist() == [28, 28]
 # (3) partial-map all-reduce
 part = torch.full((4, 4), float(rank + 1), dtype=torch.float64)
 assert float(xd.all_reduce_sum(part)[0, 0]) == 3.0
@@ -242,9 +249,25 @@ def test_sweep_state_checkpoint_roundtrip(tmp_path):
     again = SweepState.load_or_new(prefix, 10, 1, 4)
     assert again.sums == st.sums and (again.used, again.next_pos, again.attr_time) == (2, 2, 3.5)
     assert set(again.sums) == set(KEYS)
-    fresh = SweepState.load_or_new(prefix, 10, 1, 8)                 # a different split must not resume
+    fresh = SweepState.load_or_new(prefix, 10, 1, 8)                 # another world size: another file, nothing to resume
     assert fresh.used == 0 and fresh.next_pos == 0
     assert SweepState.load_or_new(None, 10, 0, 1).used == 0
+    # the same file under another split or another identity (method, model, weights, flow, image list) is refused loudly
+    from xai_engine.sweep import CheckpointMismatch, sweep_identity, model_fingerprint
+    with pytest.raises(CheckpointMismatch):
+        SweepState.load_or_new(prefix, 11, 1, 4)
+    ida = sweep_identity(attr_func="ig", model_name="R50", files="a|b|c", fused=True)
+    idb = sweep_identity(attr_func="gc", model_name="R50", files="a|b|c", fused=True)
+    assert ida != idb and ida == sweep_identity(model_name="R50", fused=True, files="a|b|c", attr_func="ig")
+    assert sweep_identity(files="x" * 500) != sweep_identity(files="x" * 499 + "y") and len(sweep_identity(files="x" * 500)) < 60
+    st2 = SweepState(10, 0, 1, ida)
+    st2.used = st2.next_pos = 10
+    st2.save(prefix)
+    assert SweepState.load_or_new(prefix, 10, 0, 1, ida).used == 10
+    with pytest.raises(CheckpointMismatch, match="different sweep"):
+        SweepState.load_or_new(prefix, 10, 0, 1, idb)
+    m1, m2 = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+    assert model_fingerprint(m1) == model_fingerprint(m1) != model_fingerprint(m2)
 
 
 def test_vitcx_and_tis_host_logic_on_reference_vectors():

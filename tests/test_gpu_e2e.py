@@ -550,8 +550,14 @@ def test_sweep_resumes_from_checkpoint(tmp_path):
         return sal[len(calls) - 1]
     with pytest.raises(RuntimeError):
         sweep_images(images, model, DEV, attr_first_two, img_hw=32, checkpoint=prefix, checkpoint_every=1)
-    st = SweepState.load_or_new(prefix, 3, 0, 1)
-    assert st.used == 2 and st.next_pos == 2
+    import json
+    st = json.load(open(SweepState.path_for(prefix, 0, 1)))
+    assert st["used"] == 2 and st["next_pos"] == 2 and "fused=True" in st["identity"]
+    from xai_engine.sweep import CheckpointMismatch
+    with pytest.raises(CheckpointMismatch):                                # the same prefix under the other flow: refused, not resumed
+        sweep_images(images, model, DEV, lambda x, t: sal[2], img_hw=32, checkpoint=prefix, checkpoint_every=1, fused=False)
+    with pytest.raises(CheckpointMismatch):                                # ... or for another method / image list
+        sweep_images(images, model, DEV, lambda x, t: sal[2], img_hw=32, checkpoint=prefix, checkpoint_every=1, identity="attr_func=gc")
     resumed, used2, _ = sweep_images(images, model, DEV, lambda x, t: sal[2], img_hw=32, checkpoint=prefix, checkpoint_every=1)
     assert used2 == 3
     for k in KEYS:
