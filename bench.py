@@ -13,6 +13,11 @@ timed region.  Images shard over ranks with no data-path collective (weak scalin
 works on its own 32 images; the timed region is bracketed by barrier + synchronize and the
 reported time is the MAX over ranks.
 
+`--workload sweep` (opt-in; the driver's contract line is the default `ig` workload) measures north_star's scaling
+target instead: the insertion/deletion sweep of BASELINE config 5 over ONE fixed list of `--sweep-images` synthetic images
+(strong scaling: image i belongs to rank i % world, the list does not grow with N), every image attributed with each of
+`--sweep-methods` and pushed through the ten metrics (224 steps each); one 88-byte all-reduce per method; value = images/s.
+
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      the IG accumulation kernel (xai_ig_accum_f32): algorithmic bytes per launch
                 ((S+2)*4N per image) / mean launch duration measured with HIP events
@@ -46,6 +51,12 @@ def parse():
     ap.add_argument("--images", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--images-per-pass", type=int, default=2, help="images x 50 interpolants per classifier pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["ig", "sweep"], default="ig", help="ig = BASELINE config 2 (the contract line); sweep = config 5, "
+                    "strong scaling over a fixed image list")
+    ap.add_argument("--sweep-images", type=int, default=1000, help="--workload sweep: length of the (global) image list")
+    ap.add_argument("--sweep-methods", default="grad,inp_x_grad,ig,lig,idg,gc", help="--workload sweep: attribution methods per image")
+    ap.add_argument("--deterministic", type=int, default=0, help="1 = torch.backends.cudnn.deterministic (MIOpen: deterministic solvers "
+                    "only; run-to-run bit-identical classifier passes, see profiles/r02_resnet_determinism_*.json)")
     ap.add_argument("--channels-last", type=int, default=0, help="1 = NHWC classifier weights (slower with MIOpen fp32 on gfx950)")
     ap.add_argument("--fuse-bn-relu", type=int, default=1, help="1 = run the classifier's eval-mode BatchNorm + ReLU (+ residual add) as one HIP "
                     "kernel per direction (xai_engine/prepare.py: fuse_bn_relu; every call site is verified bit-identical to the PyTorch "
@@ -103,6 +114,65 @@ def cpu_baseline():
                       f"{', '.join(f'{t:.2f}' for t in times)} s"}
 
 
+class SyntheticImages:
+    """Fixed global list of synthetic images (seed 1000 + i), generated on access: every rank sees
+    the same list whatever the world size, and only its own images are ever materialised."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self.n))]
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(1000 + i))
+
+
+def run_sweep_workload(args, model, dev, rank, world, prep, miopen_mode, fence, max_over_ranks):
+    """BASELINE config 5 as a strong-scaling benchmark; prints the JSON line on rank 0."""
+    from xai_engine.sweep import sweep_images, get_CNN_attr, KEYS
+    methods = [m for m in args.sweep_methods.split(",") if m]
+    images = SyntheticImages(args.sweep_images)
+    td = {"models": [model], "img_hw": H, "batch_size": 50, "device": str(dev)}
+
+    def one_pass(imgs):
+        out = {}
+        for m in methods:
+            tdm = dict(td, attr_func=m)
+            total, used, _ = sweep_images(imgs, model, dev, lambda x, t, tdm=tdm: get_CNN_attr(x, None, t, tdm), img_hw=H, batch_size=50,
+                                          rank=rank, world=world)
+            out[m] = {k: total[k] / max(used, 1) for k in KEYS}
+            out[m]["images"] = used
+        return out
+
+    log(f"sweep workload: {len(images)} images x {methods}; warmup x{args.warmup} (reduced: {2 * world} images)")
+    for _ in range(args.warmup):
+        one_pass(SyntheticImages(2 * world))
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        means = one_pass(images)
+    fence()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        n = len(images)
+        print(json.dumps({
+            "metric": "images/sec (insertion/deletion sweep: 10 metrics x 224 steps per image and method, ResNet-50 224^2)",
+            "value": n * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"insertion/deletion sweep over a fixed list of {n} synthetic 3x224x224 images (seeds 1000..), ResNet-50 "
+                                   f"(seeded random weights), methods {methods}, 224 perturbation steps, batch 50; one step = the whole list",
+                       "images": n, "methods": methods, "image_method_pairs_per_s": n * len(methods) * args.steps / dt,
+                       "warmup_step": f"a {2 * world}-image sweep per method (not the full list)", "classifier_prep": prep, "miopen": miopen_mode,
+                       "parallelism": f"image i -> rank i % {world}; one all-reduce(SUM) of 11 fp64 (88 B) per method"},
+            "metric_means": means}), flush=True)
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child torchrun (nothing has touched the
     GPU yet in this process) and pass its exit code on."""
@@ -126,7 +196,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     from xai_engine.prepare import use_tuned_miopen_db
-    tuned = bool(args.miopen_db) and not args.channels_last and not args.fold_bn and use_tuned_miopen_db(rank)
+    tuned = bool(args.miopen_db) and not args.channels_last and not args.fold_bn and not args.deterministic and use_tuned_miopen_db(rank)
     # rehearsal knobs (never set by the driver): XAI_DIST_BACKEND=gloo + XAI_FORCE_DEVICE=0 let several ranks share
     # the one GPU of a test box so that the N>1 control flow (barrier, max-over-ranks, rank-0 print) can be exercised
     backend = os.environ.get("XAI_DIST_BACKEND", "nccl")
@@ -143,6 +213,7 @@ def main():
     from xai_engine.zoo import resnet50
 
     torch.backends.cudnn.benchmark = bool(args.miopen_find) or tuned
+    torch.backends.cudnn.deterministic = bool(args.deterministic)
     model = resnet50(seed=0).to(dev)
     if args.fold_bn:
         from xai_engine.prepare import fold_batchnorm
@@ -161,6 +232,30 @@ def main():
         except ValueError as e:                       # never silently: say so in the line and run the classifier as given
             log(f"classifier fusion refused: {e}")
             prep = f"none (fusion refused: {e})"
+    miopen_mode = ("deterministic solvers only" if args.deterministic else "find mode with shipped find-db" if tuned
+                   else ("find" if args.miopen_find else "immediate mode"))
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def max_over_ranks(dt):
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        return dt
+
+    if args.workload == "sweep":
+        run_sweep_workload(args, model, dev, rank, world, prep, miopen_mode, fence, max_over_ranks)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
     with torch.no_grad():
         targets = plain_model(x).argmax(1)
     grads = torch.empty((B, STEPS_IG, C, H, W), dtype=torch.float32, device=dev)
@@ -169,12 +264,6 @@ def main():
     def step(sink=None, net=None):
         return ig_batch(x, net if net is not None else model, targets, steps=STEPS_IG, alpha_star=1, baseline=0,
                         images_per_pass=args.images_per_pass, want_abs=True, grads_buffer=grads, event_sink=sink)
-
-    def fence():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize(dev)
 
     log(f"model + inputs ready on {dev}; warmup x{args.warmup}")
     for _ in range(args.warmup):
@@ -185,13 +274,7 @@ def main():
     for _ in range(args.steps):
         step(events)
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-
+    dt = max_over_ranks(time.perf_counter() - t0)
     log(f"timed {args.steps} steps in {dt:.3f} s")
     unfused = None
     if model is not plain_model and world == 1:       # the same workload on the classifier exactly as given, for the record
@@ -210,10 +293,12 @@ def main():
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
     if rank == 0:
-        traffic = None
+        traffic = traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "ig_accum_pmc.json")     # written from a separate rocprofv3 --pmc run
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            traffic_source = ("profiles/ig_accum_pmc.json: FETCH_SIZE/WRITE_SIZE of this kernel at this shape from a separate "
+                              "rocprofv3 --pmc run (PMC passes cannot share a process with the timed run); NOT measured in this process")
         line = {
             "metric": "attributions/sec (IG 50-step ResNet-50 224^2)",
             "value": world * B * args.steps / dt,
@@ -229,10 +314,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"IG 50 steps, ResNet-50 (seeded random weights), {B}-image batch of 3x224x224 per GPU, "
                                    "alpha_star=1, baseline=0", "images_per_gpu": B, "ig_steps": STEPS_IG,
-                       "images_per_pass": args.images_per_pass, "classifier_prep": prep, "miopen": "find mode with shipped find-db" if tuned else ("find" if args.miopen_find else "immediate mode"), "parallelism": f"image-sharded x{world}, no data-path collective"},
+                       "images_per_pass": args.images_per_pass, "classifier_prep": prep, "miopen": miopen_mode, "parallelism": f"image-sharded x{world}, no data-path collective"},
             "unfused_classifier": unfused,
             "roofline": {"bound": "hbm", "kernel": "xai_ig_accum_f32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": kern_ms, "launches_timed": len(events)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -302,27 +302,36 @@ XAI_EXPORT int xai_maxpool_bwd_f32(const float* gy, const int64_t* indices, int 
   XAI_REQUIRE_PTR(gy); XAI_REQUIRE_PTR(indices); XAI_REQUIRE_PTR(gx);
   XAI_REQUIRE(planes > 0 && H > 0 && W > 0 && PH > 0 && PW > 0 && kernel > 0 && stride > 0 && pad >= 0, XAI_E_SHAPE);
   XAI_REQUIRE(static_cast<int64_t>(H) * W <= INT32_MAX, XAI_E_UNSUPPORTED);
-  XAI_REQUIRE(planes <= 65535, XAI_E_UNSUPPORTED);
-  dim3 grid(static_cast<unsigned>(xai_ceil_div(static_cast<int64_t>(H) * W, 256)), planes);
   const int nw = (kernel + stride - 1) / stride;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int pooled_rows = (kBwdRows + kernel - 2) / stride + 2;                   // upper bound of the pooled rows one tile needs
   const size_t lds = static_cast<size_t>(pooled_rows) * PW * 8;
-  if (nw <= 2 && lds <= 48 * 1024) {
-    dim3 tgrid(static_cast<unsigned>(xai_ceil_div(H, kBwdRows)), planes);
-    if (nw == 1)
-      hipLaunchKernelGGL(maxpool_bwd_tiled_kernel<1>, tgrid, dim3(256), lds, st, gy, indices, H, W, PH, PW, kernel, stride, pad, gx);
-    else
-      hipLaunchKernelGGL(maxpool_bwd_tiled_kernel<2>, tgrid, dim3(256), lds, st, gy, indices, H, W, PH, PW, kernel, stride, pad, gx);
-    return xai_launch_status();
+  // planes ride on grid.y (<= 65535): larger batches (1024 images x 64 stem channels and up) go in slabs of planes
+  constexpr int kMaxPlanes = 65535;
+  for (int p0 = 0; p0 < planes; p0 += kMaxPlanes) {
+    const int np = planes - p0 < kMaxPlanes ? planes - p0 : kMaxPlanes;
+    const float* gy_s = gy + static_cast<int64_t>(p0) * PH * PW;
+    const int64_t* idx_s = indices + static_cast<int64_t>(p0) * PH * PW;
+    float* gx_s = gx + static_cast<int64_t>(p0) * H * W;
+    if (nw <= 2 && lds <= 48 * 1024) {
+      dim3 tgrid(static_cast<unsigned>(xai_ceil_div(H, kBwdRows)), np);
+      if (nw == 1)
+        hipLaunchKernelGGL(maxpool_bwd_tiled_kernel<1>, tgrid, dim3(256), lds, st, gy_s, idx_s, H, W, PH, PW, kernel, stride, pad, gx_s);
+      else
+        hipLaunchKernelGGL(maxpool_bwd_tiled_kernel<2>, tgrid, dim3(256), lds, st, gy_s, idx_s, H, W, PH, PW, kernel, stride, pad, gx_s);
+    } else {
+      dim3 grid(static_cast<unsigned>(xai_ceil_div(static_cast<int64_t>(H) * W, 256)), np);
+      if (nw == 1)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<1>, grid, dim3(256), 0, st, gy_s, idx_s, H, W, PH, PW, kernel, stride, pad, gx_s);
+      else if (nw == 2)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<2>, grid, dim3(256), 0, st, gy_s, idx_s, H, W, PH, PW, kernel, stride, pad, gx_s);
+      else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<0>, grid, dim3(256), 0, st, gy_s, idx_s, H, W, PH, PW, kernel, stride, pad, gx_s);
+    }
+    const int rc = xai_launch_status();
+    if (rc != XAI_OK) return rc;
   }
-  if (nw == 1)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<1>, grid, dim3(256), 0, st, gy, indices, H, W, PH, PW, kernel, stride, pad, gx);
-  else if (nw == 2)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<2>, grid, dim3(256), 0, st, gy, indices, H, W, PH, PW, kernel, stride, pad, gx);
-  else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<0>, grid, dim3(256), 0, st, gy, indices, H, W, PH, PW, kernel, stride, pad, gx);
-  return xai_launch_status();
+  return XAI_OK;
 }
 
 // ---- inference-only stem: max_pool( relu( bn(x) ) ) in one pass --------------------------------------------------------

@@ -25,18 +25,10 @@ static inline bool xai_aligned16(const void* p) { return (reinterpret_cast<uintp
 
 static inline int64_t xai_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Compute units of the current device (256 on MI355X); queried once per process and device.
-static inline int xai_cu_count() {
-  static int cached[16] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-  if (cached[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached[dev] = n;
-  }
-  return cached[dev];
-}
+// Compute units of the current device (256 on MI355X).  One definition for the whole library (abi.hip): the per-device
+// value is queried once and published through a std::atomic, so concurrent first calls from several host threads race
+// only on storing the same number.
+int xai_cu_count();
 
 constexpr int kWave = 64;  // gfx950 wavefront
 

@@ -17,7 +17,8 @@
  *   - float data is IEEE fp32, index data int32, layouts are dense row-major
  *     (NCHW for images, [image][step][C][H*W] for step batches);
  *   - return value: 0 = success; <0 = argument error (XAI_E_*); >0 = hipError_t of the launch;
- *   - no global mutable state; re-entrant from several host threads on different streams.
+ *   - no global mutable state beyond a per-device compute-unit count published once through a std::atomic;
+ *     re-entrant from several host threads on different streams.
  */
 #ifndef XAI_HIP_H
 #define XAI_HIP_H
@@ -232,7 +233,8 @@ int xai_bn_relu_bwd_f32(const float* gy, const float* gy2, const float* y, const
 
 /* MaxPool2d backward from the forward's arg-max indices (int64, h * W + w within a plane), windows added in (ph, pw)
  * ascending order like PyTorch's max_pool_backward_nchw -> bit-identical; the stem of the classifiers instantiated at
- * XAI_Survey/evaluations/evaluatePerturbation.py:627-640.   gy, indices : [planes][PH*PW];  gx : [planes][H*W] */
+ * XAI_Survey/evaluations/evaluatePerturbation.py:627-640.   gy, indices : [planes][PH*PW];  gx : [planes][H*W];
+ * any plane count (more than 65 535 planes are launched in slabs) */
 int xai_maxpool_bwd_f32(const float* gy, const int64_t* indices, int planes, int H, int W, int PH, int PW,
                         int kernel, int stride, int pad, float* gx, xai_stream_t stream);
 

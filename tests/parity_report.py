@@ -234,14 +234,67 @@ def resnet_report(mode, out_path):
                            "amp": v.get("amplification_1_over_abs_orig_minus_base")}) for k, v in rep.items()}, indent=1))
 
 
+def kernels_report(mode, batch, out_path):
+    """Which module of ResNet-50 is not bit-reproducible for a `batch`-image forward in `mode`, and -- when run under
+    `rocprofv3 --kernel-trace` -- which kernels it launches: after the search the module is run alone 10 times between two
+    marker launches (the library's own sumsq kernel), so its dispatches are the ones between the markers in the trace
+    (profiles/between_markers.py lists them)."""
+    from xai_engine.zoo import resnet50
+    from xai_engine.prepare import use_tuned_miopen_db
+    torch.backends.cudnn.benchmark = use_tuned_miopen_db(0) if mode == "finddb" else False
+    torch.backends.cudnn.deterministic = (mode == "deterministic")
+    model = resnet50(seed=0).to(DEV)
+    x = torch.randn(batch, 3, 224, 224, generator=torch.Generator().manual_seed(7)).to(DEV)
+    names = {m: k for k, m in model.named_modules()}
+    runs = []
+    for _ in range(4):
+        rec = []
+        hooks = [m.register_forward_hook(lambda mod, i, o, rec=rec: rec.append((mod, i[0].detach(), o.detach().clone())))
+                 for m in model.modules() if not list(m.children())]
+        with torch.no_grad():
+            model(x)
+        for h in hooks:
+            h.remove()
+        runs.append(rec)
+    culprit = None
+    for j in range(len(runs[0])):
+        if any(not torch.equal(runs[0][j][2], r[j][2]) for r in runs[1:]):
+            culprit = runs[0][j]
+            break
+    rep = {"mode": mode, "batch": batch, "deterministic": bool(torch.backends.cudnn.deterministic), "benchmark": bool(torch.backends.cudnn.benchmark)}
+    if culprit is None:
+        rep["first_non_reproducible_module"] = None
+    else:
+        mod, inp, out = culprit
+        rep["first_non_reproducible_module"] = {"name": names[mod], "module": repr(mod), "input_shape": list(inp.shape), "output_shape": list(out.shape)}
+        torch.cuda.synchronize()
+        from xai_engine import kernels as K
+        marker = torch.ones(1, 64, device=DEV)
+        K.sumsq(marker)
+        outs = []
+        with torch.no_grad():
+            for _ in range(10):
+                outs.append(mod(inp).clone())
+        K.sumsq(marker)
+        torch.cuda.synchronize()
+        rep["module_alone_10_runs_distinct_results"] = len({o.cpu().numpy().tobytes() for o in outs})
+        rep["module_alone_max_abs_diff"] = max(float((o - outs[0]).abs().max()) for o in outs)
+    with open(out_path, "w") as f:
+        json.dump(rep, f, indent=1)
+    print(json.dumps(rep, indent=1))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gates", "resnet"])
+    ap.add_argument("--batch", type=int, default=24)
+    ap.add_argument("what", choices=["gates", "resnet", "kernels"])
     ap.add_argument("--mode", default="immediate", choices=["immediate", "deterministic", "finddb"])
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     if a.what == "gates":
         gates_report(a.out)
+    elif a.what == "kernels":
+        kernels_report(a.mode, a.batch, a.out)
     else:
         resnet_report(a.mode, a.out)

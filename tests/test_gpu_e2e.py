@@ -2,21 +2,27 @@
 signatures (image-classification-xai_amd/util/...), i.e. written the way a test of the
 reference would read.
 
-Two comparisons per feature:
+Two comparisons per feature, both through conftest.check, which records the measured error:
   (a) against the CPU oracle driving the SAME device-resident classifier -> isolates the HIP
       path from MIOpen-vs-oneDNN convolution rounding; bar 1e-5 (BASELINE.json);
-  (b) against the golden vectors the reference produced on the CPU -> includes classifier
-      rounding differences between devices.  For gradients of a ReLU network this is not a
-      rounding-sized effect: a pre-activation within ~1e-7 of zero flips its gate between
-      oneDNN and MIOpen and changes that pixel's gradient by O(1), so the bar for (b) is
-      2e-3 on IG-type maps and 1e-4 on probability curves (documented in DESIGN.md).
+  (b) against the golden vectors the reference produced on the CPU (oneDNN classifier) -> bar 1e-5 as well.
+      Measured on an MI355X (profiles/r02_parity.json, 328 comparisons): every (b) comparison is <= 5.3e-6 except
+        * IG on ig_224.npz / ig_tensor_baseline: 2.3e-4 on the 9 pixels under ONE ReLU gate of 20 070 400 whose
+          pre-activation is 5.6e-8 (fp64) -- oneDNN rounds it to -3.0e-8, MIOpen to +1.9e-7; everywhere else 4.0e-7,
+          and 3.7e-7 everywhere once the host's gates are forced on the device (profiles/r02_gate_flips.json).  So the
+          IG maps are held to 1e-5 outside the footprints of provably ill-conditioned gates (helpers.
+          ill_conditioned_footprint) and to 2x the measured 2.3e-4 inside them;
+        * getSlopes: 2.6e-5 -- a slope is the difference of two neighbouring logits (each equal to the reference's to
+          2e-7) times 49; held to 2x measured, and the logit differences it is made of to 1e-5.
+      Nothing moves between MIOpen's default immediate mode and torch.backends.cudnn.deterministic = True
+      (profiles/r02_parity_nondeterministic_mode.json is identical entry for entry); the tests run deterministic.
 """
 import numpy as np
 import pytest
 import torch
 
 from conftest import load_golden, rel_inf, check
-from helpers import tiny_from, logits_fn_of, vit_mini_from
+from helpers import tiny_from, logits_fn_of, vit_mini_from, ill_conditioned_footprint
 
 
 def _free_port():
@@ -55,7 +61,13 @@ def test_IG_signature_and_parity(attr, name):
         base_np = base.numpy() if torch.is_tensor(base) else base
         want = oig.ig(g["x"], model, steps, bs, a_star, base_np, int(target))           # (a) same device model
         check(f"IG/{name}/{key}", got, want, 1e-5, "oracle")
-        check(f"IG/{name}/{key}", got, g[key], 2e-3)                                      # (b) reference on CPU
+        # (b) reference on the CPU: the bar everywhere except under gates no fp32 convolution can decide (module docstring)
+        foot = ill_conditioned_footprint(g, g["x"], base, steps)
+        assert foot.mean() <= 0.02                                                        # <= 2 % of the pixels (855 of 50 176 at most)
+        den = np.abs(g[key]).max()
+        check(f"IG/{name}/{key}/outside_ill_conditioned_gates", got[:, ~foot] / den, g[key][:, ~foot] / den, 1e-5, absolute=True)
+        if foot.any():
+            check(f"IG/{name}/{key}/under_ill_conditioned_gates", got[:, foot] / den, g[key][:, foot] / den, 4.7e-4, absolute=True)
     assert attr.IG(x, model, 50, 7, 1, 0, DEV, target) == (0, 0, 0, 0)                  # quirk kept
 
 
@@ -83,16 +95,18 @@ def test_IDG_IDGI_and_helpers(attr):
     t = torch.tensor(int(g["target"]))
     slopes, step = attr.getSlopes(torch.zeros_like(x), x.clone(), model, 50, 25, DEV, t)
     assert step == float(g["slope_step"])
-    check("getSlopes/ig_small", slopes.cpu().numpy(), g["slopes"], 1e-3)
+    check("getSlopes/ig_small", slopes.cpu().numpy(), g["slopes"], 5.2e-5)                  # 2 x measured; see the module docstring
+    check("getSlopes/ig_small/logit_differences", np.cumsum(slopes.cpu().numpy().astype(np.float64) * step),
+          g["logits"].astype(np.float64) - g["logits"][0], 1e-5)
     al, sub = attr.getAlphaParameters(torch.from_numpy(g["slopes"]), 50, float(g["slope_step"]))
     np.testing.assert_array_equal(al.numpy(), g["idg_alphas"])
     np.testing.assert_array_equal(sub.numpy(), g["idg_substep"])
     idgi = attr.IDGI(x.clone(), model, 50, 25, 0, DEV, t).cpu().numpy()
-    check("IDGI/ig_small", idgi, oig.idgi(g["x"], model, 50, 25, 0, int(t)), 1e-4, "oracle")
-    check("IDGI/ig_small", idgi, g["idgi"], 1e-3)
+    check("IDGI/ig_small", idgi, oig.idgi(g["x"], model, 50, 25, 0, int(t)), 1e-5, "oracle")
+    check("IDGI/ig_small", idgi, g["idgi"], 1e-5)
     idg = attr.IDG(x.clone(), model, 50, 25, 0, DEV, t).cpu().numpy()
-    check("IDG/ig_small", idg, oig.idg(g["x"], model, 50, 25, 0, int(t)), 1e-4, "oracle")
-    check("IDG/ig_small", idg, g["idg"], 5e-3)            # slope weights are differences of near-equal logits
+    check("IDG/ig_small", idg, oig.idg(g["x"], model, 50, 25, 0, int(t)), 1e-5, "oracle")
+    check("IDG/ig_small", idg, g["idg"], 1e-5)
     xg = x.clone().to(DEV)
     ig_ = attr.input_grad(xg, model, t)
     check("input_grad/ig_small", ig_.cpu().numpy(), g["input_grad"], 1e-5)
@@ -134,8 +148,8 @@ def test_smoothGrad_vs_the_seeded_reference_run(attr):
         np.testing.assert_array_equal(o_noisy, g[f"{tag}_noisy_imgs"])
         check(f"smoothGrad/{tag}/total_gradients", total.cpu().numpy(), o_total, 1e-5, "oracle")
         check(f"smoothGrad/{tag}/mean", mean.cpu().numpy(), o_mean, 1e-5, "oracle")
-        check(f"smoothGrad/{tag}/total_gradients", total.cpu().numpy(), g[f"{tag}_total_gradients"], 2e-3)
-        check(f"smoothGrad/{tag}/mean", mean.cpu().numpy(), g[f"{tag}_mean"], 2e-3)
+        check(f"smoothGrad/{tag}/total_gradients", total.cpu().numpy(), g[f"{tag}_total_gradients"], 1e-5)
+        check(f"smoothGrad/{tag}/mean", mean.cpu().numpy(), g[f"{tag}_mean"], 1e-5)
         torch.manual_seed(int(g["seed"]))
         only = attr.smoothGrad("IG", x.clone(), model, steps, base, t, DEV, sigma_spread=spread, samples=samples)       # CPU input, vis=False
         np.testing.assert_array_equal(only.cpu().numpy(), mean.cpu().numpy())
@@ -185,7 +199,7 @@ def test_single_run_return_tuples(fixture):
                 assert int(r) == int(w) == int(gold), (tag, i)
                 continue
             check(f"single_run/{fixture}/{tag}/ret{i}", r, w, 1e-5, "oracle")        # (a) oracle on the same device model
-            check(f"single_run/{fixture}/{tag}/ret{i}", r, gold, 1e-4)               # (b) reference on the CPU
+            check(f"single_run/{fixture}/{tag}/ret{i}", r, gold, 1e-5)               # (b) reference on the CPU
     if pm is None:
         AIC = importlib.import_module("util.test_methods.AICTestFunctions")
         score, resp = AIC.AICMetric(model, HW, "del", int(g["step"]), torch.zeros_like).single_run(
@@ -206,7 +220,7 @@ def test_device_blur_substrate_and_mode_asserts():
     n, corrected, ent, dens, norm = m.single_run(x.clone(), g["saliency"], DEV, max_batch_size=50)
     assert n == 225
     for i, r in enumerate((n, corrected, ent, dens, norm)):
-        check(f"single_run_device_blur/perturb_224/MAS_ins/ret{i}", r, g[f"MAS_ins_ret{i}"], 1e-4)
+        check(f"single_run_device_blur/perturb_224/MAS_ins/ret{i}", r, g[f"MAS_ins_ret{i}"], 1.1e-5)   # measured 5.3e-6
     with pytest.raises(AssertionError):
         MAS.MASMetric(model, 224 * 224, "insert", 224, substrate_fn=blur)
     assert abs(MAS.auc(np.linspace(0, 1, 225)) - 0.5) < 1e-15
@@ -255,7 +269,7 @@ def test_run_perturbation_and_fused_sweep_match_reference_counters():
         ref = dict(zip(KEYS, g[f"counter_{i}"]))
         for k in KEYS:
             check(f"fused_vs_8_runs/sweep_small/{i}/{k}", b[k], a[k], 1e-6, "8-run flow", absolute=True)   # dedupe changes nothing
-            check(f"run_perturbation/sweep_small/{i}/{k}", a[k], ref[k], 1e-4, absolute=True)              # vs the reference on the CPU
+            check(f"run_perturbation/sweep_small/{i}/{k}", a[k], ref[k], 1e-5, absolute=True)              # vs the reference on the CPU
 
 
 class _WithLayer4(torch.nn.Module):
@@ -281,7 +295,7 @@ def test_get_CNN_attr_dispatch():
         "ig": np.abs(g["ig"].sum(0)), "lig": np.abs(g["lig"].sum(0)), "idg": np.abs(g["idg"].sum(0)),
         "grad": np.abs(g["input_grad"].sum(0)), "inp_x_grad": np.abs((g["x"][0] * g["input_grad"]).sum(0)),
     }
-    tol = {"ig": 2e-3, "lig": 2e-3, "idg": 5e-3, "grad": 1e-5, "inp_x_grad": 1e-5}
+    tol = {"ig": 1e-5, "lig": 1e-5, "idg": 1e-5, "grad": 1e-5, "inp_x_grad": 1e-5}       # ig_small has no ill-conditioned gate that flips
     for name, w in want.items():
         got = get_CNN_attr(x.clone(), None, t, dict(td, attr_func=name))
         assert got.shape == (32, 32) and got.dtype == np.float32
@@ -307,7 +321,7 @@ def test_sweep_images_single_rank_and_csv(tmp_path):
     total, used, attr_t = sweep_images(images, model, DEV, lambda x, t: sal_of[next(calls)], img_hw=32, batch_size=50)
     assert used == 3
     for j, k in enumerate(KEYS):
-        check(f"sweep_images/sum3/{k}", total[k], sum(g[f"counter_{i}"][j] for i in range(3)), 3e-4, absolute=True)
+        check(f"sweep_images/sum3/{k}", total[k], sum(g[f"counter_{i}"][j] for i in range(3)), 1e-5, absolute=True)
     path = tmp_path / "pert_test_results" / "T" / "ig_3_images.csv"
     write_csv(str(path), total, used, attr_t, 1.0)
     rows = [r.split(",") for r in open(path).read().strip().splitlines()]
@@ -327,27 +341,27 @@ def test_vit_pixel_ig_and_attention_ig(attr):
     t = torch.tensor(int(g["target"]))
     got = attr.IG(x.clone(), model, 50, 25, 1, 0, DEV, t).cpu().numpy()
     check("vit_mini/pixel_ig", got, oig.ig(g["x"], model, 50, 25, 1, 0, int(t)), 1e-5, "oracle")
-    check("vit_mini/pixel_ig", got, g["ig"], 1e-4)             # smooth network (GELU/softmax): no gate flips
+    check("vit_mini/pixel_ig", got, g["ig"], 1e-5)             # smooth network (GELU/softmax): no gates
     b = Baselines(model)
     a = b.IG(x.clone(), t, steps=20, device=DEV).cpu().numpy()
     assert a.shape == (1, 4, 4)
     check("vit_mini/attn_ig", a, ovit.attention_ig(model, g["x"], int(t), 20), 1e-5, "oracle")
-    check("vit_mini/attn_ig", a, g["attn_ig"], 1e-4)
-    check("vit_mini/raw_attn", b.generate_raw_attn(x, DEV).cpu().numpy(), g["raw_attn"], 1e-4)
-    check("vit_mini/attn_grad", b.generate_grad(x.clone(), t, DEV).cpu().numpy(), g["attn_grad"], 1e-4)
+    check("vit_mini/attn_ig", a, g["attn_ig"], 1e-5)
+    check("vit_mini/raw_attn", b.generate_raw_attn(x, DEV).cpu().numpy(), g["raw_attn"], 1e-5)
+    check("vit_mini/attn_grad", b.generate_grad(x.clone(), t, DEV).cpu().numpy(), g["attn_grad"], 1e-5)
     xd = x.to(DEV)
-    check("vit_mini/naive_rollout", b.generate_naive_rollout(xd)[0].cpu().numpy(), g["naive_rollout"], 1e-4)
-    check("vit_mini/rollout", b.generate_rollout(xd)[0].cpu().numpy(), g["rollout"], 1e-4)
+    check("vit_mini/naive_rollout", b.generate_naive_rollout(xd)[0].cpu().numpy(), g["naive_rollout"], 1e-5)
+    check("vit_mini/rollout", b.generate_rollout(xd)[0].cpu().numpy(), g["rollout"], 1e-5)
     st, w, fin, last_attn, last_grad = b.generate_transition_attention_maps(x.clone(), t, steps=20, device=DEV)
     for got, key in ((st, "tam_states"), (w, "tam_w"), (fin, "tam_final"), (last_attn, "tam_last_attn"), (last_grad, "tam_last_grad")):
         assert got.shape == g[key].shape
-        check(f"vit_mini/{key}", got.detach().cpu().numpy(), g[key], 1e-4)
+        check(f"vit_mini/{key}", got.detach().cpu().numpy(), g[key], 1e-5)
     np.testing.assert_array_equal(w.cpu().numpy(), a)                    # T-Attn's integrated weights are Baselines.IG's map
-    check("vit_mini/attn_attr", b.attn_attr(x.clone(), t, device=DEV).cpu().numpy(), g["attn_attr"], 1e-4)
+    check("vit_mini/attn_attr", b.attn_attr(x.clone(), t, device=DEV).cpu().numpy(), g["attn_attr"], 1e-5)
     bi, bi_R = b.bidirectional(x.clone(), t, steps=20, start_layer=1, device=DEV)
-    check("vit_mini/bi_attr", bi.cpu().numpy(), g["bi_attr"], 1e-4)
-    check("vit_mini/bi_R", bi_R.cpu().numpy(), g["bi_R"], 1e-4)
-    check("vit_mini/bi_mae", b.bidirectional(x.clone(), t, steps=20, start_layer=1, mae=True, device=DEV).cpu().numpy(), g["bi_mae"], 1e-4)
+    check("vit_mini/bi_attr", bi.cpu().numpy(), g["bi_attr"], 1e-5)
+    check("vit_mini/bi_R", bi_R.cpu().numpy(), g["bi_R"], 1e-5)
+    check("vit_mini/bi_mae", b.bidirectional(x.clone(), t, steps=20, start_layer=1, mae=True, device=DEV).cpu().numpy(), g["bi_mae"], 1e-5)
 
 
 def test_evaluate_perturbation_on_a_directory(tmp_path):
@@ -468,6 +482,60 @@ def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
         assert f"rank {r} ok" in o
 
 
+def _bench(*flags, ranks=1):
+    """python bench.py ... as the driver starts it (bench.py relaunches itself under torchrun for --gpus > 1); with two ranks
+    both share cuda:0 and talk over gloo.  -> (the parsed JSON line, stdout)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    if ranks > 1:
+        env.update(XAI_DIST_BACKEND="gloo", XAI_FORCE_DEVICE="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), *flags], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # exactly ONE JSON line, printed by rank 0
+    return json.loads(lines[0]), r.stdout
+
+
+def test_bench_contract_line_with_one_and_two_ranks():
+    """bench.py's N > 1 control flow (launcher, barrier, max-over-ranks, rank-0 print) rehearsed on the one GPU of the test box:
+    two ranks share cuda:0 over gloo (XAI_DIST_BACKEND / XAI_FORCE_DEVICE -- never set by the driver)."""
+    small = ("--steps", "1", "--warmup", "1", "--images", "4", "--no-cpu-baseline", "--miopen-db", "0")
+    one, _ = _bench(*small, ranks=1)
+    two, _ = _bench(*small, ranks=2)
+    for line, n in ((one, 1), (two, 2)):
+        assert line["n_gpus"] == n and line["steps"] == 1 and line["warmup"] == 1 and line["scaling"] == "weak"
+        assert line["unit"] == "attributions/s" and line["dtype"] == "f32" and line["vs_baseline"] is None
+        assert line["config"]["images_per_gpu"] == 4 and "workload" in line["config"]
+        rf = line["roofline"]
+        assert rf["bound"] == "hbm" and rf["kernel"] == "xai_ig_accum_f32" and 0 < rf["frac"] < 1 and "traffic_source" in rf
+        assert abs(line["value"] - n * 4 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]        # whole-job aggregate
+    assert "cpu_baseline" not in two
+    # two ranks on ONE card: the aggregate can only be about what one rank gets alone
+    assert 0.4 <= two["value"] / one["value"] <= 1.6, (one["value"], two["value"])
+
+
+def test_bench_sweep_workload_is_strong_scaling_over_one_fixed_list():
+    """--workload sweep: the same 4-image list with one and with two ranks gives the same per-method metric means (image i ->
+    rank i % world, one 88-byte all-reduce per method); deterministic MIOpen solvers, so only the order of the final sums differs."""
+    flags = ("--workload", "sweep", "--sweep-images", "4", "--sweep-methods", "grad,gc", "--steps", "1", "--warmup", "0", "--deterministic", "1",
+             "--no-cpu-baseline")
+    one, _ = _bench(*flags, ranks=1)
+    two, _ = _bench(*flags, ranks=2)
+    for line, n in ((one, 1), (two, 2)):
+        assert line["n_gpus"] == n and line["scaling"] == "strong" and line["unit"] == "images/s" and line["config"]["images"] == 4
+        assert abs(line["value"] - 4 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    for m in ("grad", "gc"):
+        assert one["metric_means"][m]["images"] == two["metric_means"][m]["images"] == 4
+        for k, v in one["metric_means"][m].items():
+            assert abs(v - two["metric_means"][m][k]) <= 1e-9, (m, k, v, two["metric_means"][m][k])
+
+
 def test_CLIP_test_info_branch():
     """The CLIP branch of the metrics (MASTestFunctions.py:143-159,277-281; get_CLIP_pred at
     evaluatePerturbation.py:68-74): similarities = encode_image(x) @ embeddings.T, softmax at T = 0.1."""
@@ -527,7 +595,7 @@ def test_get_VIT_attr_dispatch():
         if name in key:                        # bi_attn's default start_layer=4 exceeds the mini model's depth: shape check only
             want = torch.nn.functional.interpolate(torch.from_numpy(g[key[name]])[None], size=(32, 32), mode="bilinear",
                                                    align_corners=False, antialias=True)[0, 0].abs().numpy()
-            check(f"get_VIT_attr/{name}", got, want, 1e-4)
+            check(f"get_VIT_attr/{name}", got, want, 1e-5)
     with pytest.raises(SystemExit):
         get_VIT_attr(x, None, t, dict(td, attr_func="nope"))
 
@@ -663,7 +731,7 @@ def test_TIS_stages_and_end_to_end():
         check(f"TIS/{tag}/scores", scores.cpu().numpy(), g[f"{tag}_scores"], 1e-5)
         check(f"TIS/{tag}/sal", tis(x).cpu().numpy(), g[f"{tag}_sal"], 1e-5)             # class_idx=None -> predicted class
         tis.normalise = True
-        check(f"TIS/{tag}/sal_norm", tis(x, class_idx=int(pred)).cpu().numpy(), g[f"{tag}_sal_norm"], 2e-5)
+        check(f"TIS/{tag}/sal_norm", tis(x, class_idx=int(pred)).cpu().numpy(), g[f"{tag}_sal_norm"], 1e-5)
         if tag == "a":
             assert np.array_equal(idx[0].cpu().numpy(), g["a_idx"])
             assert np.array_equal(tis.mask_input(x, idx[0][:3], baseline="zero").cpu().numpy(), g["a_masked_zero"])
@@ -781,22 +849,23 @@ def test_fuse_bn_relu_model_sites_verified_names_and_hooks_kept():
     t_in = int(oc[0].argmax())
     inner_a = gradcam_saliency(model, model.layer2, x[:1], t_in, (64, 64))
     inner_b = gradcam_saliency(forked, forked.layer2, x[:1], t_in, (64, 64))
-    assert rel_inf(inner_b.cpu().numpy(), inner_a.cpu().numpy()) <= 1e-3
+    check("fuse_bn_relu/gradcam_layer2_forked", inner_b.cpu().numpy(), inner_a.cpu().numpy(), 1e-3, "unfused classifier")
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     oa, ob = model(xa), fused(xb)
     (ga,), (gb,) = torch.autograd.grad(oa[:, 3].sum(), xa), torch.autograd.grad(ob[:, 3].sum(), xb)
     # whole-model: equal up to the run-to-run noise of MIOpen's convolutions (the original differs from itself by as much;
     # a ReLU gate flipped by that noise moves single gradient pixels, hence the loose bound -- bit-identity is per call site)
-    assert rel_inf(ob.detach().cpu().numpy(), oa.detach().cpu().numpy()) <= 1e-5
-    assert rel_inf(gb.cpu().numpy(), ga.cpu().numpy()) <= 2e-2
-    assert rel_inf(oc.detach().cpu().numpy(), oa.detach().cpu().numpy()) <= 1e-5 and rel_inf(gc_.cpu().numpy(), ga.cpu().numpy()) <= 2e-2
+    check("fuse_bn_relu/logits", ob.detach().cpu().numpy(), oa.detach().cpu().numpy(), 1e-5, "unfused classifier")
+    check("fuse_bn_relu/input_gradient", gb.cpu().numpy(), ga.cpu().numpy(), 2e-2, "unfused classifier")
+    check("fuse_bn_relu/logits_forked", oc.detach().cpu().numpy(), oa.detach().cpu().numpy(), 1e-5, "unfused classifier")
+    check("fuse_bn_relu/input_gradient_forked", gc_.cpu().numpy(), ga.cpu().numpy(), 2e-2, "unfused classifier")
     t = int(oa[0].argmax())
     cam_a = gradcam_saliency(model, model.layer4, x[:1], t, (64, 64))
     cam_b = gradcam_saliency(fused, fused.layer4, x[:1], t, (64, 64))          # forward hook on layer4 still fires
-    assert rel_inf(cam_b.cpu().numpy(), cam_a.cpu().numpy()) <= 1e-3
+    check("fuse_bn_relu/gradcam_layer4", cam_b.cpu().numpy(), cam_a.cpu().numpy(), 1e-3, "unfused classifier")
     ig_a = IG(x[:1], model, 20, 10, 1, 0, DEV, torch.tensor(t))
     ig_b = IG(x[:1], fused, 20, 10, 1, 0, DEV, torch.tensor(t))
-    assert rel_inf(ig_b.cpu().numpy(), ig_a.cpu().numpy()) <= 2e-2             # ReLU-gate flips from conv noise, as between any two runs
+    check("fuse_bn_relu/IG", ig_b.cpu().numpy(), ig_a.cpu().numpy(), 2e-2, "unfused classifier")
     with pytest.raises(ValueError):
         fuse_bn_relu(torch.nn.Sequential(torch.nn.Conv2d(3, 3, 1)).to(DEV))
     # inference (no autograd): the stem runs as one bn+relu+max-pool kernel, bit-identical to the three PyTorch kernels
@@ -807,11 +876,13 @@ def test_fuse_bn_relu_model_sites_verified_names_and_hooks_kept():
         assert one is not None and torch.equal(one, model.maxpool(torch.relu(model.bn1(stem))))
         odd = torch.randn(2, 16, 37, 53, device=DEV)
         assert torch.equal(stem_inference(odd, model.bn1, model.maxpool), model.maxpool(torch.relu(model.bn1(odd))))
-        assert rel_inf(fused(x).cpu().numpy(), model(x).cpu().numpy()) <= 1e-5
+        check("fuse_bn_relu/logits_inference_stem", fused(x).cpu().numpy(), model(x).cpu().numpy(), 1e-5, "unfused classifier")
     assert stem_inference(stem.clone().requires_grad_(True), model.bn1, model.maxpool) is None      # autograd needs the full activation
     # the stem's max-pool backward: bit-identical to PyTorch's, also for odd sizes and other geometries
     from xai_engine.prepare import max_pool
-    for shape, (k, s_, p) in (((3, 5, 112, 112), (3, 2, 1)), ((2, 4, 31, 45), (3, 2, 1)), ((2, 3, 20, 20), (2, 2, 0)), ((1, 2, 17, 9), (3, 1, 1))):
+    # (1100, 64, ...): N*C = 70 400 planes > 65 535, the grid.y limit -- the ABI goes through them in slabs
+    for shape, (k, s_, p) in (((3, 5, 112, 112), (3, 2, 1)), ((2, 4, 31, 45), (3, 2, 1)), ((2, 3, 20, 20), (2, 2, 0)), ((1, 2, 17, 9), (3, 1, 1)),
+                              ((1100, 64, 10, 9), (3, 2, 1))):
         pool = torch.nn.MaxPool2d(k, s_, p)
         xa = torch.randn(shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7)).round(decimals=1)   # ties on purpose
         xb = xa.clone()
@@ -870,25 +941,41 @@ def test_fuse_bn_relu_on_a_torchvision_style_basic_block_network():
         xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
         oa, ob = model(xa), fused(xb)
         (ga,), (gb,) = torch.autograd.grad(oa[:, 1].sum(), xa), torch.autograd.grad(ob[:, 1].sum(), xb)
-        assert rel_inf(ob.detach().cpu().numpy(), oa.detach().cpu().numpy()) <= 1e-5
-        assert rel_inf(gb.cpu().numpy(), ga.cpu().numpy()) <= 2e-2
+        check(f"fuse_bn_relu/basicblock/fork{int(fork)}/logits", ob.detach().cpu().numpy(), oa.detach().cpu().numpy(), 1e-5, "unfused classifier")
+        check(f"fuse_bn_relu/basicblock/fork{int(fork)}/input_gradient", gb.cpu().numpy(), ga.cpu().numpy(), 2e-2, "unfused classifier")
 
 
-def test_cli_runs_resnet50_with_the_fused_classifier(tmp_path):
-    """python -m xai_engine.evaluate_perturbation on a directory of three synthetic files, ResNet-50 (seeded random weights),
-    Grad-CAM, --fuse_bn_relu: the selection pre-pass and the sweep run through the fused classifier; a CSV (when the
-    reference's sanity filter lets a random-weight prediction through at all) has the reference's twelve rows."""
+def test_cli_runs_resnet50_with_the_fused_classifier(tmp_path, capsys):
+    """python -m xai_engine.evaluate_perturbation on a directory of synthetic files, ResNet-50 (seeded random weights), Grad-CAM,
+    --fuse_bn_relu: the selection pre-pass and the sweep run through the fused classifier.  What the reference's sanity filter
+    (evaluatePerturbation.py:569) lets through with random weights is computed independently with harness.select_images, and the
+    CLI must then have written exactly the CSV for that count -- or none, and said so, when nothing passes."""
     from PIL import Image
     from xai_engine import evaluate_perturbation as cli
+    from xai_engine import harness
+    from xai_engine.zoo import resnet50
     root = tmp_path / "val"
     root.mkdir()
     rng = np.random.default_rng(11)
-    for i in range(1, 4):
-        blocks = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
-        Image.fromarray(np.kron(blocks, np.ones((32, 32, 1), dtype=np.uint8))).save(root / f"ILSVRC2012_val_{i:08d}.JPEG", format="PNG")
+    for i in range(1, 9):
+        if i % 2:                                          # noise images (high-frequency: blurring changes the prediction) and blocky ones
+            arr = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+        else:
+            arr = np.kron(rng.integers(0, 256, (8, 8, 3), dtype=np.uint8), np.ones((32, 32, 1), dtype=np.uint8))
+        Image.fromarray(arr).save(root / f"ILSVRC2012_val_{i:08d}.JPEG", format="PNG")
+    model = resnet50().to(DEV).eval()
+    expect = harness.select_images({"models": [model], "imagenet_dataset": str(root), "img_hw": 224, "image_count": 2, "device": DEV,
+                                    "normalize": (harness.CNN_MEAN, harness.CNN_STD)})
     out = tmp_path / "res"
     cli.main(["--model", "R50", "--attr_func", "gc", "--image_count", "2", "--dataset_path", str(root), "--fuse_bn_relu",
               "--out_dir", str(out)])
-    for f in (out / "R50").glob("gc_*_images.csv"):
-        rows = f.read_text().strip().splitlines()
-        assert len(rows) == 12 and rows[0].startswith("MAS_ins,") and rows[-2].startswith("Attr Avg Runtime,")
+    said = capsys.readouterr().out
+    assert f"{len(expect)} images" in said
+    files = sorted((out / "R50").glob("*.csv")) if (out / "R50").exists() else []
+    if not expect:
+        assert files == []
+        return
+    assert [f.name for f in files] == ["gc_2_images.csv"]
+    rows = files[0].read_text().strip().splitlines()
+    assert len(rows) == 12 and rows[0].startswith("MAS_ins,") and rows[-2].startswith("Attr Avg Runtime,") and rows[-1].startswith("Total Runtime,")
+    assert all(np.isfinite(float(r.split(",")[1])) for r in rows)
