@@ -196,7 +196,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     from xai_engine.prepare import use_tuned_miopen_db
-    tuned = bool(args.miopen_db) and not args.channels_last and not args.fold_bn and not args.deterministic and use_tuned_miopen_db(rank)
+    tuned = bool(args.miopen_db) and not args.channels_last and not args.fold_bn and use_tuned_miopen_db(rank)
     # rehearsal knobs (never set by the driver): XAI_DIST_BACKEND=gloo + XAI_FORCE_DEVICE=0 let several ranks share
     # the one GPU of a test box so that the N>1 control flow (barrier, max-over-ranks, rank-0 print) can be exercised
     backend = os.environ.get("XAI_DIST_BACKEND", "nccl")
@@ -232,8 +232,8 @@ def main():
         except ValueError as e:                       # never silently: say so in the line and run the classifier as given
             log(f"classifier fusion refused: {e}")
             prep = f"none (fusion refused: {e})"
-    miopen_mode = ("deterministic solvers only" if args.deterministic else "find mode with shipped find-db" if tuned
-                   else ("find" if args.miopen_find else "immediate mode"))
+    miopen_mode = ("find mode with shipped find-db" if tuned else ("find" if args.miopen_find else "immediate mode")) + \
+        (", deterministic solvers only" if args.deterministic else "")
 
     def fence():
         if world > 1:

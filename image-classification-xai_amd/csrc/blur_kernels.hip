@@ -31,11 +31,12 @@ __global__ __launch_bounds__(kBlock) void blur_sep_kernel(const float* __restric
   const int64_t plane = static_cast<int64_t>(blockIdx.z) * H * W;
   const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   // halo staging: a wave per row, lanes along the row (no integer division, coalesced row reads).  Loads are issued in
-  // groups of 8 (4 rows x 2 column steps) into registers before any of them is stored to LDS: with a store between
-  // every two loads the staging was one HBM latency per element and dominated the kernel.
+  // groups of 32 (16 rows x 2 column steps) into registers before any of them is stored to LDS: with a store between
+  // every two loads the staging was one HBM latency per element and dominated the kernel; with groups of 8 it was still
+  // four latencies per tile (62 halo rows at 31 taps / 16 rows per round), now it is one.
   {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int kRows = 4, kWaves = kBlock >> 6;
+    constexpr int kRows = 16, kWaves = kBlock >> 6;
     for (int base = wave; base < IH; base += kRows * kWaves) {
       float v[kRows][2];
 #pragma unroll

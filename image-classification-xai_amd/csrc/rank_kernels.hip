@@ -237,7 +237,11 @@ XAI_EXPORT int xai_rank_f32(const float* sal, int n_seg, int64_t hw, int32_t* or
   const int n_tiles = tiles_of(hw);
   // zero the identity flags and the four histograms of every map
   const size_t fw = front_words(n_seg, n_tiles);
+#ifdef XAI_RANK_ZERO_WITH_MEMSET   // scratch builds of profiles/experiments/exp_graph_memset.py only; never defined by the Makefile
+  if (hipMemsetAsync(w, 0, fw * sizeof(uint32_t), st) != hipSuccess) return xai_launch_status();
+#else
   hipLaunchKernelGGL(rank_zero_kernel, dim3(static_cast<unsigned>(std::min<size_t>(1024, (fw + kBlock - 1) / kBlock))), dim3(kBlock), 0, st, w, fw);
+#endif
   const dim3 grid(n_tiles, n_seg), blk(kBlock);
   hipLaunchKernelGGL(rank_hist_kernel<true>, grid, blk, 0, st, sal, hw, n_tiles, 0, w);
   for (int pass = 0; pass < 4; ++pass) {

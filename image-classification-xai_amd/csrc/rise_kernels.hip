@@ -6,8 +6,11 @@
 // what skimage.transform.resize(order=1, mode='reflect') runs.  Tap positions/weights are
 // computed in fp64 (they are exact-to-fp32 then), the 4-tap blend in fp32.
 //
-// K4 (write-bound, C*H*W*4 B per mask): grid = (pixel tiles, masks); the mask's s*s grid
-//    bytes sit in LDS, a lane produces 4 pixels x C channels with 16-byte stores.
+// K4 (write-bound, C*H*W*4 B per mask): grid = (pixel tiles, masks); a lane produces 4 pixels x C channels with
+//    16-byte stores.  s == 8 (the RISE default): the grid is one 64-bit word per mask in SGPRs, no LDS; other s: the
+//    mask's s*s grid bytes sit in LDS.  The kernel is bound by the HBM write stream, not by the mask arithmetic: with
+//    the arithmetic removed it is no faster, and a separable LDS-staged form (column-interpolated rows + one vertical
+//    lerp per pixel) is 4-7 % slower (csrc/tune/tune_rise.hip, profiles/r02_tune_rise.txt).
 // K5 (compute/LDS-bound, almost no HBM traffic): grid = (pixel tiles, mask slices); tap tables
 //    for every up-sampled row/column live in LDS, mask grids are staged in LDS 256 at a time,
 //    a lane owns one pixel and accumulates score*mask in fp64; one fp64 atomic per pixel per
@@ -136,16 +139,30 @@ __device__ __forceinline__ float blend8(uint2 rows, const Tap& r, const Tap& c, 
   return fminf(fmaxf(v, lo), hi);
 }
 
+// NT: non-temporal stores for batches that cannot stay cache-resident anyway (see xai_rise_apply_f32); C3: the usual
+// three channels -- the lane's three image quads are loaded before the mask arithmetic, so their latency hides behind it.
+typedef float rise_f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ void rise_store(float* p, float4 v) {
+  if (NT) { const rise_f4 t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<rise_f4*>(p)); }
+  else st4(p, v);
+}
+
+template <bool NT, bool C3>
 __global__ __launch_bounds__(kBlock) void rise_apply_kernel_s8(const uint8_t* __restrict__ grid, const int32_t* __restrict__ shift,
                                                                int cell_h, int cell_w, double rh, double rw, const float* __restrict__ image, int C,
                                                                int H, int W, float* __restrict__ masked, float* __restrict__ masks) {
   const int n = blockIdx.y;
-  const unsigned long long bits = pack_grid8(grid + static_cast<int64_t>(n) * 64);
-  const float hi = bits != 0ull ? 1.f : 0.f;
-  const float lo = bits == ~0ull ? 1.f : 0.f;
   const int64_t hw = static_cast<int64_t>(H) * W;
   const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 4;
   if (p >= hw) return;
+  float4 img[3];
+  if (C3 && masked) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) img[c] = ld4(image + c * hw + p);
+  }
+  const unsigned long long bits = pack_grid8(grid + static_cast<int64_t>(n) * 64);
+  const float hi = bits != 0ull ? 1.f : 0.f;
+  const float lo = bits == ~0ull ? 1.f : 0.f;
   const int y = static_cast<int>(static_cast<uint32_t>(p) / static_cast<uint32_t>(W)), x = static_cast<int>(p - static_cast<int64_t>(y) * W);
   const int sx = shift[2 * n + 1];
   const Tap tr = make_tap(y + shift[2 * n], 8, rh);
@@ -155,12 +172,17 @@ __global__ __launch_bounds__(kBlock) void rise_apply_kernel_s8(const uint8_t* __
   m.y = blend8(rows, tr, make_tap(x + 1 + sx, 8, rw), lo, hi);
   m.z = blend8(rows, tr, make_tap(x + 2 + sx, 8, rw), lo, hi);
   m.w = blend8(rows, tr, make_tap(x + 3 + sx, 8, rw), lo, hi);
-  if (masks) st4(masks + static_cast<int64_t>(n) * hw + p, m);
+  if (masks) rise_store<NT>(masks + static_cast<int64_t>(n) * hw + p, m);
   if (masked) {
     float* o = masked + static_cast<int64_t>(n) * C * hw + p;
-    for (int c = 0; c < C; ++c) {
-      const float4 v = ld4(image + c * hw + p);
-      st4(o + c * hw, make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w));
+    if (C3) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rise_store<NT>(o + c * hw, make_float4(img[c].x * m.x, img[c].y * m.y, img[c].z * m.z, img[c].w * m.w));
+    } else {
+      for (int c = 0; c < C; ++c) {
+        const float4 v = ld4(image + c * hw + p);
+        rise_store<NT>(o + c * hw, make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w));
+      }
     }
   }
 }
@@ -277,7 +299,18 @@ XAI_EXPORT int xai_rise_apply_f32(const uint8_t* grid, const int32_t* shift, int
   const bool vec = (W % 4 == 0) && xai_aligned16(image) && xai_aligned16(masked_out) && xai_aligned16(masks_out);
   if (vec && s == 8 && (reinterpret_cast<uintptr_t>(grid) & 7u) == 0) {
     dim3 g(static_cast<unsigned>(xai_ceil_div(hw, kBlock * 4)), n_masks);
-    hipLaunchKernelGGL(rise_apply_kernel_s8, g, dim3(kBlock), 0, st, grid, shift, cell_h, cell_w, rh, rw, image, C, H, W, masked_out, masks_out);
+    // Store policy by what the classifier will find: a batch that fits the 256 MiB Infinity Cache with room to spare is
+    // stored normally (the convolution that consumes it next reads it from cache); a larger one cannot stay resident
+    // anyway and is streamed with non-temporal stores, which on this part write 13-15 % faster
+    // (csrc/tune/tune_rise.hip, profiles/r02_tune_rise.txt: 1000 masks 104.9 -> 92.4 us).
+    const int64_t out_bytes = static_cast<int64_t>(n_masks) * hw * 4 * ((masked_out ? C : 0) + (masks_out ? 1 : 0));
+    const bool nt = out_bytes > (int64_t(128) << 20);
+    const bool c3 = (C == 3);
+#define XAI_RISE_S8(NT, C3) \
+    hipLaunchKernelGGL((rise_apply_kernel_s8<NT, C3>), g, dim3(kBlock), 0, st, grid, shift, cell_h, cell_w, rh, rw, image, C, H, W, masked_out, masks_out)
+    if (nt) { if (c3) XAI_RISE_S8(true, true); else XAI_RISE_S8(true, false); }
+    else    { if (c3) XAI_RISE_S8(false, true); else XAI_RISE_S8(false, false); }
+#undef XAI_RISE_S8
   } else if (vec) {
     dim3 g(static_cast<unsigned>(xai_ceil_div(hw, kBlock * 4)), n_masks);
     hipLaunchKernelGGL(rise_apply_kernel_v4, g, dim3(kBlock), s * s, st, grid, shift, s, cell_h, cell_w, rh, rw, image, C, H, W, masked_out, masks_out);

@@ -74,37 +74,53 @@ class _PerturbationMetric:
             return (self.model.encode_image(images) @ emb.squeeze().T).detach()
 
     # ---- the shared device pipeline ------------------------------------------------------
-    def _run(self, img_tensor, saliency_map, device, patch_mask, max_batch_size, clip_info=None, want_density=False):
+    def _run(self, img_tensor, saliency_map, device, patch_mask, max_batch_size, clip_info=None, want_density=False,
+             want_embeddings=False):
         dev = hip_device(device)
         n_steps, step_size, batches = curves.step_plan(self.HW, self.step_size, max_batch_size, patch_mask, self.ALWAYS_LEFTOVER)
         if patch_mask is not None:
             self.step_size = step_size                      # the reference overwrites it too (:92)
         temp = 0.1 if clip_info is not None else None       # CLIP similarities are softmaxed at T = 0.1
 
+        # return_embeddings (MASTestFunctions.py:121-133,283-296): after the pass over the original image and after every
+        # step batch, the block outputs the hooked ViT retained (`block.get_block_out()`) and the arg-max classes are kept --
+        # on the device, one (num_blocks, batch, tokens, dim) tensor per pass; the substrate probe in between is not recorded
+        kept = {"on": False, "emb": [], "cls": []}
+
         def stats(images, target, out=None, offset=0):
             lg = self._logits(images, clip_info)
+            if kept["on"]:
+                kept["emb"].append(torch.stack([blk.get_block_out().detach() for blk in self.model.blocks]))
+                kept["cls"].append(lg.argmax(1))
             return _Probe(lg / temp if temp else lg, target, out, offset)
 
         img = img_tensor.to(dev, torch.float32).contiguous()
         substrate = self.substrate_fn(img_tensor).to(dev, torch.float32).contiguous()
+        kept["on"] = want_embeddings
         if clip_info is None:
             orig = stats(img, None)
         else:
             orig = stats(clip_info["input"].to(dev), None)
         target = orig.argmax                                 # int32 (1,) on the device, never synced
+        kept["on"] = False
         sub = stats(substrate, target)
+        kept["on"] = want_embeddings
         start, finish = (substrate, img) if self._inserting() else (img, substrate)
 
         # pixel order -> flip step per pixel
         seg = total = None
+        salient_order = None
         if patch_mask is None:
             sal = torch.as_tensor(np.ascontiguousarray(saliency_map, dtype=np.float32)).reshape(1, self.HW).to(dev)
             order, rk = K.rank(sal)
             flip = K.flip_steps(rk[0], self._descending(), step_size)
+            if want_embeddings:                              # (1, HW) like np.flip(np.argsort(...)) / np.argsort(...) (:209-212)
+                asc = order.cpu().numpy().astype(np.int64)
+                salient_order = asc[:, ::-1].copy() if self._descending() else asc
             if want_density:
                 seg, total = K.segment_sums(sal[0], order[0], self._descending(), step_size, n_steps)
         else:
-            flip_np, _ = curves.patch_flip_steps(saliency_map, patch_mask, self.HW, n_steps, self._descending())
+            flip_np, salient_order = curves.patch_flip_steps(saliency_map, patch_mask, self.HW, n_steps, self._descending())
             flip = torch.from_numpy(flip_np).to(dev)
             if want_density:
                 seg, total = curves.patch_density_sums(saliency_map, flip_np, self.HW, n_steps)
@@ -123,7 +139,19 @@ class _PerturbationMetric:
             if torch.is_tensor(seg):
                 seg, total = seg.cpu().numpy(), total.cpu().numpy()[0]
             out["density"] = curves.density_curve(seg, total, self._inserting())
+        if want_embeddings:
+            emb, cls = kept["emb"], kept["cls"]              # [original, batch 1, batch 2, ...]
+            if self.mode == "ins":                           # the reference appends the original image's entry LAST for 'ins' (:375-377)
+                emb, cls = emb[1:] + emb[:1], cls[1:] + cls[:1]
+            out["embeddings"] = torch.cat(emb, dim=1).cpu().numpy()
+            out["classes"] = torch.cat(cls, dim=0).cpu().numpy()
+            out["salient_order"] = salient_order
         return out
+
+    def _embeddings_tuple(self, r):
+        """(embeddings (num_blocks, n_steps + 1, tokens, dim), classes (n_steps + 1,), raw model response, salient order)
+        -- the return_embeddings=True result of MASMetric / RISEMetric (MASTestFunctions.py:370-381, RISETestFunctions.py:223-234)"""
+        return r["embeddings"], r["classes"], r["response"], r["salient_order"]
 
 
 class MASMetric(_PerturbationMetric):
@@ -132,9 +160,14 @@ class MASMetric(_PerturbationMetric):
 
     def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, special_version=False,
                    return_embeddings=False, CLIP_test_info=None):
-        if special_version or return_embeddings:
-            raise NotImplementedError("special_version (cvxopt QP smoothing) and return_embeddings are outside the accelerated path")
-        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info, want_density=True)
+        if special_version:
+            raise NotImplementedError("special_version (cvxopt QP smoothing of the curve) is outside the accelerated path")
+        if return_embeddings and CLIP_test_info is not None:
+            raise NotImplementedError("return_embeddings reads model.blocks[i].get_block_out(): hooked ViT classifiers only, as in the reference")
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info, want_density=True,
+                      want_embeddings=return_embeddings)
+        if return_embeddings:
+            return self._embeddings_tuple(r)
         if CLIP_test_info is not None:
             r["entropy"] = np.ones(r["n_steps"] + 1)        # the reference's CLIP branch never fills it (:143-159,:277-281)
         norm = curves.monotone_normalise(r["response"], r["baseline_pred"], r["original_pred"], falling=(self.mode != 'ins'))
@@ -147,9 +180,9 @@ class RISEMetric(_PerturbationMetric):
     MODES = ('del', 'ins', 'morf', 'lerf')
 
     def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, return_embeddings=False):
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, want_embeddings=return_embeddings)
         if return_embeddings:
-            raise NotImplementedError("return_embeddings is outside the accelerated path")
-        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size)
+            return self._embeddings_tuple(r)
         norm = curves.monotone_normalise(r["response"], r["baseline_pred"], r["original_pred"], falling=(self.mode != 'ins'))
         return r["n_steps"] + 1, r["entropy"], norm
 

@@ -127,9 +127,17 @@ class Block(nn.Module):
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
+        self.block_out = None
+
+    def get_block_out(self):
+        """output of the last forward pass (reference ViT_new_timm.py:285,297-312): what `single_run(return_embeddings=True)` reads"""
+        return self.block_out
+
     def forward(self, x, register_hook=False):
         x = x + self.attn(self.norm1(x), register_hook)
-        return x + self.mlp(self.norm2(x))
+        x = x + self.mlp(self.norm2(x))
+        self.block_out = x
+        return x
 
 
 class PatchEmbed(nn.Module):

@@ -159,11 +159,11 @@ def resnet_report(mode, out_path):
     from xai_engine.sweep import PerturbationSweep, run_perturbation, KEYS
     from xai_engine.ig import IG
     from xai_engine.prepare import use_tuned_miopen_db, fuse_bn_relu
-    if mode == "finddb":
+    if mode in ("finddb", "finddb_deterministic"):
         torch.backends.cudnn.benchmark = use_tuned_miopen_db(0)
     else:
         torch.backends.cudnn.benchmark = False
-    torch.backends.cudnn.deterministic = (mode == "deterministic")
+    torch.backends.cudnn.deterministic = mode in ("deterministic", "finddb_deterministic")
     rep = {"mode": mode, "benchmark": bool(torch.backends.cudnn.benchmark), "deterministic": bool(torch.backends.cudnn.deterministic),
            "device": torch.cuda.get_device_name(0)}
     model = resnet50(seed=0).to(DEV)
@@ -234,15 +234,15 @@ def resnet_report(mode, out_path):
                            "amp": v.get("amplification_1_over_abs_orig_minus_base")}) for k, v in rep.items()}, indent=1))
 
 
-def kernels_report(mode, batch, out_path):
+def kernels_report(mode, batch, out_path, module=None):
     """Which module of ResNet-50 is not bit-reproducible for a `batch`-image forward in `mode`, and -- when run under
     `rocprofv3 --kernel-trace` -- which kernels it launches: after the search the module is run alone 10 times between two
     marker launches (the library's own sumsq kernel), so its dispatches are the ones between the markers in the trace
     (profiles/between_markers.py lists them)."""
     from xai_engine.zoo import resnet50
     from xai_engine.prepare import use_tuned_miopen_db
-    torch.backends.cudnn.benchmark = use_tuned_miopen_db(0) if mode == "finddb" else False
-    torch.backends.cudnn.deterministic = (mode == "deterministic")
+    torch.backends.cudnn.benchmark = use_tuned_miopen_db(0) if mode in ("finddb", "finddb_deterministic") else False
+    torch.backends.cudnn.deterministic = mode in ("deterministic", "finddb_deterministic")
     model = resnet50(seed=0).to(DEV)
     x = torch.randn(batch, 3, 224, 224, generator=torch.Generator().manual_seed(7)).to(DEV)
     names = {m: k for k, m in model.named_modules()}
@@ -261,7 +261,13 @@ def kernels_report(mode, batch, out_path):
         if any(not torch.equal(runs[0][j][2], r[j][2]) for r in runs[1:]):
             culprit = runs[0][j]
             break
-    rep = {"mode": mode, "batch": batch, "deterministic": bool(torch.backends.cudnn.deterministic), "benchmark": bool(torch.backends.cudnn.benchmark)}
+    if culprit is None and module:                 # under the profiler the race may not show: still run the named module alone
+        culprit = next(r for r in runs[0] if names[r[0]] == module)
+        rep_named = True
+    else:
+        rep_named = False
+    rep = {"mode": mode, "batch": batch, "deterministic": bool(torch.backends.cudnn.deterministic), "benchmark": bool(torch.backends.cudnn.benchmark),
+           "module_was_named_not_found": rep_named}
     if culprit is None:
         rep["first_non_reproducible_module"] = None
     else:
@@ -287,14 +293,15 @@ def kernels_report(mode, batch, out_path):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=24)
+    ap.add_argument("--module", default=None, help="kernels: run this module alone when no non-reproducible one shows up")
     ap.add_argument("what", choices=["gates", "resnet", "kernels"])
-    ap.add_argument("--mode", default="immediate", choices=["immediate", "deterministic", "finddb"])
+    ap.add_argument("--mode", default="immediate", choices=["immediate", "deterministic", "finddb", "finddb_deterministic"])
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     if a.what == "gates":
         gates_report(a.out)
     elif a.what == "kernels":
-        kernels_report(a.mode, a.batch, a.out)
+        kernels_report(a.mode, a.batch, a.out, a.module)
     else:
         resnet_report(a.mode, a.out)

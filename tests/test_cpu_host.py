@@ -299,3 +299,29 @@ def test_fuse_bn_relu_is_a_no_op_off_the_gpu():
         assert torch.equal(fused(x), model(x))
     with pytest.raises(ValueError):
         fuse_bn_relu(torch.nn.Linear(3, 3))
+
+
+def test_tolerances_are_tied_to_measured_errors():
+    """profiles/r02_parity.json is the ledger conftest.check wrote on an MI355X (tests/parity_report.sh): every comparison of
+    the GPU suite with its measured error and the tolerance asserted.  No tolerance may exceed max(the 1e-5 bar, 2 x the largest error measured in its test family):
+    a tolerance is a measurement with head-room, not slack."""
+    import json
+    from conftest import BAR
+    led = json.load(open(os.path.join(ROOT, "profiles", "r02_parity.json")))
+    assert led["meta"]["exitstatus"] == 0 and led["meta"]["deterministic"] is True
+    rows = led["comparisons"]
+    assert len(rows) >= 300
+    # a tolerance above the bar is shared by the cases of one test family (first path component of the name): the family's
+    # largest measured error must reach at least half of it
+    fam = {}
+    for r in rows:
+        if r["tol"] > BAR * (1 + 1e-9):
+            key = (r["name"].split("/")[0], r["against"], r["tol"])
+            fam[key] = max(fam.get(key, 0.0), r["measured"])
+    loose = {k: v for k, v in fam.items() if k[2] > 2 * v * (1 + 1e-9)}
+    assert not loose, loose
+    golden = [r for r in rows if r["against"] == "golden"]
+    assert len(golden) >= 150 and all(r["measured"] <= r["tol"] for r in rows)
+    # what is above the bar is exactly what DESIGN.md section 2 explains: one ReLU gate of ig_224 and the finite-difference slopes
+    above = sorted({r["name"] for r in golden if r["measured"] > BAR})
+    assert above == ["IG/ig_224.npz/ig_tensor_baseline/under_ill_conditioned_gates", "getSlopes/ig_small"], above

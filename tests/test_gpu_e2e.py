@@ -63,11 +63,11 @@ def test_IG_signature_and_parity(attr, name):
         check(f"IG/{name}/{key}", got, want, 1e-5, "oracle")
         # (b) reference on the CPU: the bar everywhere except under gates no fp32 convolution can decide (module docstring)
         foot = ill_conditioned_footprint(g, g["x"], base, steps)
-        assert foot.mean() <= 0.02                                                        # <= 2 % of the pixels (855 of 50 176 at most)
+        assert foot.mean() <= 0.05                                                        # a few dozen 3x3 footprints (36 of 1024 px, 855 of 50 176)
         den = np.abs(g[key]).max()
         check(f"IG/{name}/{key}/outside_ill_conditioned_gates", got[:, ~foot] / den, g[key][:, ~foot] / den, 1e-5, absolute=True)
         if foot.any():
-            check(f"IG/{name}/{key}/under_ill_conditioned_gates", got[:, foot] / den, g[key][:, foot] / den, 4.7e-4, absolute=True)
+            check(f"IG/{name}/{key}/under_ill_conditioned_gates", got[:, foot] / den, g[key][:, foot] / den, 4.6e-4, absolute=True)
     assert attr.IG(x, model, 50, 7, 1, 0, DEV, target) == (0, 0, 0, 0)                  # quirk kept
 
 
@@ -95,7 +95,7 @@ def test_IDG_IDGI_and_helpers(attr):
     t = torch.tensor(int(g["target"]))
     slopes, step = attr.getSlopes(torch.zeros_like(x), x.clone(), model, 50, 25, DEV, t)
     assert step == float(g["slope_step"])
-    check("getSlopes/ig_small", slopes.cpu().numpy(), g["slopes"], 5.2e-5)                  # 2 x measured; see the module docstring
+    check("getSlopes/ig_small", slopes.cpu().numpy(), g["slopes"], 5.1e-5)                  # 2 x measured (2.56e-5); see the module docstring
     check("getSlopes/ig_small/logit_differences", np.cumsum(slopes.cpu().numpy().astype(np.float64) * step),
           g["logits"].astype(np.float64) - g["logits"][0], 1e-5)
     al, sub = attr.getAlphaParameters(torch.from_numpy(g["slopes"]), 50, float(g["slope_step"]))
@@ -220,7 +220,7 @@ def test_device_blur_substrate_and_mode_asserts():
     n, corrected, ent, dens, norm = m.single_run(x.clone(), g["saliency"], DEV, max_batch_size=50)
     assert n == 225
     for i, r in enumerate((n, corrected, ent, dens, norm)):
-        check(f"single_run_device_blur/perturb_224/MAS_ins/ret{i}", r, g[f"MAS_ins_ret{i}"], 1.1e-5)   # measured 5.3e-6
+        check(f"single_run_device_blur/perturb_224/MAS_ins/ret{i}", r, g[f"MAS_ins_ret{i}"], 1e-5)   # measured 5.3e-6
     with pytest.raises(AssertionError):
         MAS.MASMetric(model, 224 * 224, "insert", 224, substrate_fn=blur)
     assert abs(MAS.auc(np.linspace(0, 1, 225)) - 0.5) < 1e-15
@@ -580,6 +580,62 @@ def test_CLIP_test_info_branch():
     assert aic.shape == (33,) and aic[0] == 1
 
 
+def test_return_embeddings_of_MAS_and_RISE_metrics_on_the_hooked_vit():
+    """single_run(return_embeddings=True) (MASTestFunctions.py:121-133,283-296,370-381; RISETestFunctions.py:95,195,223): the
+    per-block token embeddings of the original image and of every step image, the arg-max classes, the RAW response and the
+    salient order.  The reference's own hooked model for this branch (ViT_new_timm, needs timm) cannot be imported here, so the
+    4-tuple is checked against the oracle's image sequence pushed through the same model with forward hooks (parity unpinned
+    against the reference itself)."""
+    from util.test_methods import MASTestFunctions as MAS, RISETestFunctions as RISE
+    from oracle import perturb as op
+    g = load_golden("vit_mini.npz")
+    model = vit_mini_from(g, DEV)
+    x = torch.from_numpy(g["x"])
+    sal = np.random.default_rng(7).standard_normal((32, 32)).astype(np.float32)
+    HW, step, bs = 1024, 128, 3                                   # 8 steps in batches of 3, 3, 2
+
+    def by_hand(mode, patch_mask=None):
+        plan = op.Plan(HW, step, bs, patch_mask)
+        groups, order = op.flip_groups(sal, HW, plan, patch_mask, mode != "lerf")
+        zeros = np.zeros_like(g["x"])
+        start, finish = (zeros, g["x"]) if mode == "ins" else (g["x"], zeros)
+        seq = np.stack(list(op.sequence(start, finish, groups)))
+        outs = []
+        hooks = [b.register_forward_hook(lambda m, i, o, k=k: outs[-1].__setitem__(k, o.detach().cpu())) for k, b in enumerate(model.blocks)]
+        embs, classes, resp = [], [], []
+        with torch.no_grad():
+            lo = 0
+            batches = [g["x"]] + [seq[i:i + bs] for i in range(0, len(seq), bs)]
+            for b in batches:
+                outs.append([None] * len(model.blocks))
+                lg = model(torch.from_numpy(np.ascontiguousarray(b)).to(DEV))
+                embs.append(torch.stack(outs[-1]))
+                classes.append(lg.argmax(1).cpu())
+                resp.append(torch.softmax(lg, 1).cpu())
+        for h in hooks:
+            h.remove()
+        t = int(classes[0][0])
+        if mode == "ins":
+            embs, classes = embs[1:] + embs[:1], classes[1:] + classes[:1]
+        return torch.cat(embs, 1).numpy(), torch.cat(classes).numpy(), torch.cat(resp[1:])[:, t].numpy(), order
+
+    for cls, mode in ((MAS.MASMetric, "del"), (MAS.MASMetric, "ins"), (MAS.MASMetric, "lerf"), (RISE.RISEMetric, "del"), (RISE.RISEMetric, "ins")):
+        emb, classes, response, order = cls(model, HW, mode, step, torch.zeros_like).single_run(x.clone(), sal, DEV, max_batch_size=bs,
+                                                                                                return_embeddings=True)
+        w_emb, w_cls, w_resp, w_order = by_hand(mode)
+        assert emb.shape == (2, 9, 17, 32) and classes.shape == (9,) and response.shape == (9,)
+        np.testing.assert_array_equal(emb, w_emb)
+        np.testing.assert_array_equal(classes, w_cls)
+        check(f"return_embeddings/{cls.__name__}/{mode}/response", response[1:], w_resp, 1e-5, "oracle sequence + hooks")
+        np.testing.assert_array_equal(np.asarray(order).reshape(-1), np.asarray(w_order).reshape(-1))
+        assert np.asarray(order).shape == (1, HW)
+    # patch_mask branch: the salient order is the patch order
+    pm = torch.arange(16).reshape(4, 4).repeat_interleave(8, 0).repeat_interleave(8, 1)
+    emb, classes, response, order = MAS.MASMetric(model, HW, "del", step, torch.zeros_like).single_run(
+        x.clone(), sal, DEV, patch_mask=pm, max_batch_size=50, return_embeddings=True)
+    assert emb.shape == (2, 17, 17, 32) and np.asarray(order).shape == (16,) and sorted(np.asarray(order).tolist()) == list(range(16))
+
+
 def test_get_VIT_attr_dispatch():
     from helpers import vit_mini_from
     from xai_engine.sweep import get_VIT_attr, VIT_ATTR_FUNCS
@@ -849,23 +905,24 @@ def test_fuse_bn_relu_model_sites_verified_names_and_hooks_kept():
     t_in = int(oc[0].argmax())
     inner_a = gradcam_saliency(model, model.layer2, x[:1], t_in, (64, 64))
     inner_b = gradcam_saliency(forked, forked.layer2, x[:1], t_in, (64, 64))
-    check("fuse_bn_relu/gradcam_layer2_forked", inner_b.cpu().numpy(), inner_a.cpu().numpy(), 1e-3, "unfused classifier")
+    check("fuse_bn_relu/gradcam_layer2_forked", inner_b.cpu().numpy(), inner_a.cpu().numpy(), 1e-5, "unfused classifier")
     xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     oa, ob = model(xa), fused(xb)
     (ga,), (gb,) = torch.autograd.grad(oa[:, 3].sum(), xa), torch.autograd.grad(ob[:, 3].sum(), xb)
-    # whole-model: equal up to the run-to-run noise of MIOpen's convolutions (the original differs from itself by as much;
-    # a ReLU gate flipped by that noise moves single gradient pixels, hence the loose bound -- bit-identity is per call site)
+    # whole-model: with deterministic MIOpen solvers (conftest) the fused classifier is bit-identical to the unfused one,
+    # logits and input gradients (measured 0, profiles/r02_parity.json); without the flag the convolutions' own run-to-run
+    # noise flips ReLU gates and single gradient pixels move by up to 1e-2 -- in the unfused model against itself just as much
     check("fuse_bn_relu/logits", ob.detach().cpu().numpy(), oa.detach().cpu().numpy(), 1e-5, "unfused classifier")
-    check("fuse_bn_relu/input_gradient", gb.cpu().numpy(), ga.cpu().numpy(), 2e-2, "unfused classifier")
+    check("fuse_bn_relu/input_gradient", gb.cpu().numpy(), ga.cpu().numpy(), 1e-5, "unfused classifier")
     check("fuse_bn_relu/logits_forked", oc.detach().cpu().numpy(), oa.detach().cpu().numpy(), 1e-5, "unfused classifier")
-    check("fuse_bn_relu/input_gradient_forked", gc_.cpu().numpy(), ga.cpu().numpy(), 2e-2, "unfused classifier")
+    check("fuse_bn_relu/input_gradient_forked", gc_.cpu().numpy(), ga.cpu().numpy(), 1e-5, "unfused classifier")
     t = int(oa[0].argmax())
     cam_a = gradcam_saliency(model, model.layer4, x[:1], t, (64, 64))
     cam_b = gradcam_saliency(fused, fused.layer4, x[:1], t, (64, 64))          # forward hook on layer4 still fires
-    check("fuse_bn_relu/gradcam_layer4", cam_b.cpu().numpy(), cam_a.cpu().numpy(), 1e-3, "unfused classifier")
+    check("fuse_bn_relu/gradcam_layer4", cam_b.cpu().numpy(), cam_a.cpu().numpy(), 1e-5, "unfused classifier")
     ig_a = IG(x[:1], model, 20, 10, 1, 0, DEV, torch.tensor(t))
     ig_b = IG(x[:1], fused, 20, 10, 1, 0, DEV, torch.tensor(t))
-    check("fuse_bn_relu/IG", ig_b.cpu().numpy(), ig_a.cpu().numpy(), 2e-2, "unfused classifier")
+    check("fuse_bn_relu/IG", ig_b.cpu().numpy(), ig_a.cpu().numpy(), 1e-5, "unfused classifier")
     with pytest.raises(ValueError):
         fuse_bn_relu(torch.nn.Sequential(torch.nn.Conv2d(3, 3, 1)).to(DEV))
     # inference (no autograd): the stem runs as one bn+relu+max-pool kernel, bit-identical to the three PyTorch kernels
@@ -942,7 +999,7 @@ def test_fuse_bn_relu_on_a_torchvision_style_basic_block_network():
         oa, ob = model(xa), fused(xb)
         (ga,), (gb,) = torch.autograd.grad(oa[:, 1].sum(), xa), torch.autograd.grad(ob[:, 1].sum(), xb)
         check(f"fuse_bn_relu/basicblock/fork{int(fork)}/logits", ob.detach().cpu().numpy(), oa.detach().cpu().numpy(), 1e-5, "unfused classifier")
-        check(f"fuse_bn_relu/basicblock/fork{int(fork)}/input_gradient", gb.cpu().numpy(), ga.cpu().numpy(), 2e-2, "unfused classifier")
+        check(f"fuse_bn_relu/basicblock/fork{int(fork)}/input_gradient", gb.cpu().numpy(), ga.cpu().numpy(), 1e-5, "unfused classifier")
 
 
 def test_cli_runs_resnet50_with_the_fused_classifier(tmp_path, capsys):
