@@ -59,10 +59,13 @@ __device__ __forceinline__ SegPtrs seg_ptrs(uint32_t* ws, int seg, int n_seg, in
   return p;
 }
 
-// zero the front of the scratch (flags + histograms).  A kernel rather than hipMemsetAsync: captured through
-// torch.cuda.graph the library's memset once appeared not to take effect on replay (tests/test_gpu_kernels.py graph test);
-// a stand-alone captured memset node (tune/repro_graph_memset.hip) does replay, so that observation is not trusted -- the
-// kernel costs the same and is kept.
+// zero the front of the scratch (flags + histograms).  A kernel, NOT hipMemsetAsync: on the HIP runtime the PyTorch
+// 2.10+rocm7.0 wheel bundles (torch/lib/libamdhip64.so, roc-7.0.2, hipRuntimeGetVersion 70051831 -- the runtime every torch
+// process runs on, whatever /opt/rocm holds) a memset node of a hipGraph takes effect on the FIRST hipGraphLaunch only: every
+// later launch leaves all words untouched, for any size, offset, capture mode or instantiate flag, with or without torch in
+// the process; on ROCm 7.2.0's own runtime (70226015) the same programs replay correctly
+// (csrc/tune/repro_graph_memset{2,3}.hip; profiles/r02_repro_graph_memset*.txt, r02_exp_graph_memset_torch.json).
+// The C ABI promises graph-capturable launches, so no entry point of this library may enqueue a memset.
 __global__ __launch_bounds__(kBlock) void rank_zero_kernel(uint32_t* __restrict__ w, size_t n_words) {
   const size_t stride = static_cast<size_t>(gridDim.x) * kBlock;
   for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_words; i += stride) w[i] = 0u;

@@ -38,6 +38,10 @@ def build_parser():
     p.add_argument("--eight_runs", action="store_true", help="drive the eight single_run calls like the reference instead of the fused sweep")
     p.add_argument("--fuse_bn_relu", action="store_true", help="CNN models: run eval-mode BatchNorm + ReLU (+ residual add) through the fused "
                    "HIP kernels (prepare.fuse_bn_relu; every call site is verified bit-identical to the PyTorch kernels first)")
+    p.add_argument("--nondeterministic", action="store_true", help="allow MIOpen's non-deterministic solvers (atomics-based split-K implicit "
+                   "GEMMs: run-to-run noise of ~1e-6 on probabilities, profiles/r02_resnet_determinism_*.json).  Default: "
+                   "torch.backends.cudnn.deterministic = True -- bit-reproducible sweeps, fused flow == eight-run flow exactly, at the "
+                   "throughput of MIOpen's immediate mode")
     p.add_argument("--out_dir", type=str, default="pert_test_results")
     p.add_argument("--checkpoint", type=str, default=None, help="path prefix for per-rank resume files (the reference loses a crashed run)")
     return p
@@ -50,6 +54,7 @@ def main(argv=None):
     if args.attr_func not in (VIT_ATTR_FUNCS if "VIT" in args.model else CNN_ATTR_FUNCS):
         print("Model-attribution mismatch, please use --help.")
         raise SystemExit(1)
+    torch.backends.cudnn.deterministic = not args.nondeterministic
     rank, world, device = xd.init_from_env()
     if world == 1:
         device = torch.device("cuda", args.cuda_num)

@@ -534,6 +534,32 @@ def test_kernels_run_on_the_callers_stream_and_are_graph_capturable(K):
         np.testing.assert_array_equal(imgs_g.cpu().numpy(), K.perturb_batch(start, finish, K.flip_steps(r2[0], True, 32), 0, 8).cpu().numpy())
 
 
+def test_graph_replays_see_a_fresh_zero_fill_every_time(K):
+    """K8's histogram words must be re-zeroed by EVERY replay of a captured sort.  On the HIP runtime bundled with the torch
+    wheel a memset graph node only takes effect on the first launch (profiles/r02_repro_graph_memset3.txt),
+    so the library zero-fills with a kernel; here the workspace is dirtied between replays, which makes a skipped zero-fill
+    a wrong sort instead of a lucky one."""
+    from xai_engine import _lib
+    lib = _lib.load()
+    sal = dev(np.random.default_rng(60).standard_normal((2, 5000)).astype(np.float32))
+    ws = torch.empty(lib.xai_rank_workspace_bytes(2, 5000), dtype=torch.uint8, device=DEV)
+    order = torch.empty((2, 5000), dtype=torch.int32, device=DEV)
+    rk = torch.empty_like(order)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            rc = lib.xai_rank_f32(sal.data_ptr(), 2, 5000, order.data_ptr(), rk.data_ptr(), ws.data_ptr(), ws.numel(), side.cuda_stream)
+    assert rc == 0
+    for seed in range(61, 66):
+        sal.copy_(dev(np.random.default_rng(seed).standard_normal((2, 5000)).astype(np.float32)))
+        ws.fill_(0xAB)
+        graph.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(order.cpu().numpy(), np.argsort(sal.cpu().numpy(), axis=1, kind="stable"))
+
+
 # ------------------------------------------------------------------------------ degenerate and ragged shapes
 def test_edge_shapes(K):
     from oracle import ig as oig, perturb as op, rise as orise
