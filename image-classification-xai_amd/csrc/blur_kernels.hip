@@ -17,15 +17,22 @@ static_assert(TW == 64, "the index arithmetic below assumes 64-wide tiles");
 // two-pass form agree bit for bit.  (FMA on purpose: the reference is a dense 961-tap conv2d whose summation order
 // cannot be reproduced by any separable form; parity is the 1e-5 bar, and the multiply-add count is what bounds this
 // kernel.)
-template <int TH>
+//
+// KLEN = 31 (the reference's gkern(31, 31), evaluatePerturbation.py:456): the horizontal pass reads each lane's 36-dword row
+// segment with nine 16-byte LDS reads and runs the 31 taps out of registers.  With the sliding window of dword reads
+// (KLEN = 0, any odd length) lanes sit 4 dwords apart, so quads q and q+8 of a row share a bank: a 2-way conflict on
+// 34 ds_read_b32 per lane, 2 108 of the 2 652 LDS cycles of a tile.  The 16-byte reads are conflict-free with a row pitch
+// of 96 dwords once odd rows visit their quads in the order q ^ 8 (a 16-lane LDS group holds quads {0-3, 12-15} of one
+// row and {4-11} of the next: the rotation puts the second row on banks 16-47, the first stays on 0-15 / 48-63).
+template <int TH, int KLEN>
 __global__ __launch_bounds__(kBlock) void blur_sep_kernel(const float* __restrict__ x, const float* __restrict__ k1d, int klen,
                                                           int H, int W, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int r = klen / 2;
   const int IH = TH + 2 * r, IW = TW + 2 * r;
-  // odd row pitch: in the horizontal pass a wave reads 4 rows x 16 quads with a 4-float stride inside a row, and an odd
-  // pitch puts the four rows on the four bank residues mod 4 (conflict-free) instead of on the same one
-  const int P = IW | 1;
+  // KLEN == 0: odd row pitch -- a wave reads 4 rows x 16 quads with a 4-float stride inside a row, and an odd pitch puts the
+  // four rows on the four bank residues mod 4 instead of on the same one.  KLEN == 31: pitch 96 (see above)
+  const int P = KLEN ? 96 : (IW | 1);
   float* tin = lds;                            // [IH][P]
   float* tmid = lds + ((IH * P + 3) & ~3);     // [IH][TW], 16-byte aligned
   const int64_t plane = static_cast<int64_t>(blockIdx.z) * H * W;
@@ -65,16 +72,34 @@ __global__ __launch_bounds__(kBlock) void blur_sep_kernel(const float* __restric
   }
   __syncthreads();
   for (int i = threadIdx.x; i < IH * (TW / 4); i += kBlock) {
-    const int ly = i >> 4, q = i & 15;                 // TW / 4 == 16 quads per row
-    const float* row = tin + ly * P + 4 * q;
+    const int ly = i >> 4;                             // TW / 4 == 16 quads per row
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    float w0 = row[0], w1 = row[1], w2 = row[2];
+    int q;
+    if (KLEN) {
+      q = (i & 15) ^ ((ly & 1) << 3);
+      const float* row = tin + ly * P + 4 * q;
+      float w[KLEN + 5];                               // KLEN + 3 values are used; 36 = nine quads for KLEN = 31
+#pragma unroll
+      for (int v = 0; v < (KLEN + 5) / 4; ++v) {
+        const float4 t = ld4(row + 4 * v);
+        w[4 * v] = t.x; w[4 * v + 1] = t.y; w[4 * v + 2] = t.z; w[4 * v + 3] = t.w;
+      }
+#pragma unroll
+      for (int j = 0; j < KLEN; ++j) {
+        const float k = k1d[j];
+        a0 = __builtin_fmaf(k, w[j], a0); a1 = __builtin_fmaf(k, w[j + 1], a1); a2 = __builtin_fmaf(k, w[j + 2], a2); a3 = __builtin_fmaf(k, w[j + 3], a3);
+      }
+    } else {
+      q = i & 15;
+      const float* row = tin + ly * P + 4 * q;
+      float w0 = row[0], w1 = row[1], w2 = row[2];
 #pragma unroll 8
-    for (int j = 0; j < klen; ++j) {
-      const float w3 = row[j + 3];
-      const float k = k1d[j];
-      a0 = __builtin_fmaf(k, w0, a0); a1 = __builtin_fmaf(k, w1, a1); a2 = __builtin_fmaf(k, w2, a2); a3 = __builtin_fmaf(k, w3, a3);
-      w0 = w1; w1 = w2; w2 = w3;
+      for (int j = 0; j < klen; ++j) {
+        const float w3 = row[j + 3];
+        const float k = k1d[j];
+        a0 = __builtin_fmaf(k, w0, a0); a1 = __builtin_fmaf(k, w1, a1); a2 = __builtin_fmaf(k, w2, a2); a3 = __builtin_fmaf(k, w3, a3);
+        w0 = w1; w1 = w2; w2 = w3;
+      }
     }
     st4(tmid + ly * TW + 4 * q, make_float4(a0, a1, a2, a3));
   }
@@ -148,17 +173,21 @@ XAI_EXPORT int xai_blur_sep_f32(const float* x, const float* k1d, int klen, int 
   // 16-row tiles while that is what it takes to give every CU a couple of workgroups (one image: 168 tiles), 32-row tiles
   // (a third less halo per output) for batches
   const int64_t tiles16 = static_cast<int64_t>(B) * C * ((W + TW - 1) / TW) * ((H + 15) / 16);
-  const size_t lds32 = static_cast<size_t>((32 + 2 * r) * ((TW + 2 * r) | 1) + 3 + (32 + 2 * r) * TW) * sizeof(float);
+  const int pitch = klen == 31 ? 96 : ((TW + 2 * r) | 1);
+  const size_t lds32 = static_cast<size_t>((32 + 2 * r) * pitch + 3 + (32 + 2 * r) * TW) * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(stream);
   if (tiles16 >= 8 * static_cast<int64_t>(xai_cu_count()) && lds32 <= 64 * 1024) {
     constexpr int TH = 32;
     const size_t lds = lds32;
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * C);
-    hipLaunchKernelGGL(blur_sep_kernel<TH>, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), x, k1d, klen, H, W, out);
+    if (klen == 31) hipLaunchKernelGGL((blur_sep_kernel<TH, 31>), grid, dim3(kBlock), lds, st, x, k1d, klen, H, W, out);
+    else            hipLaunchKernelGGL((blur_sep_kernel<TH, 0>), grid, dim3(kBlock), lds, st, x, k1d, klen, H, W, out);
   } else {
     constexpr int TH = 16;
-    const size_t lds = static_cast<size_t>((TH + 2 * r) * ((TW + 2 * r) | 1) + 3 + (TH + 2 * r) * TW) * sizeof(float);
+    const size_t lds = static_cast<size_t>((TH + 2 * r) * pitch + 3 + (TH + 2 * r) * TW) * sizeof(float);
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B * C);
-    hipLaunchKernelGGL(blur_sep_kernel<TH>, grid, dim3(kBlock), lds, static_cast<hipStream_t>(stream), x, k1d, klen, H, W, out);
+    if (klen == 31) hipLaunchKernelGGL((blur_sep_kernel<TH, 31>), grid, dim3(kBlock), lds, st, x, k1d, klen, H, W, out);
+    else            hipLaunchKernelGGL((blur_sep_kernel<TH, 0>), grid, dim3(kBlock), lds, st, x, k1d, klen, H, W, out);
   }
   return xai_launch_status();
 }
