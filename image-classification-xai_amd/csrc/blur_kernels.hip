@@ -79,9 +79,13 @@ __global__ __launch_bounds__(kBlock) void blur_sep_kernel(const float* __restric
       q = (i & 15) ^ ((ly & 1) << 3);
       const float* row = tin + ly * P + 4 * q;
       float w[KLEN + 5];                               // KLEN + 3 values are used; 36 = nine quads for KLEN = 31
+      // explicit LDS address space + 16-byte vector type: left to itself the compiler re-splits these loads into
+      // ds_read2_b32 / ds_read2_b64 (which bring the 2-way conflict back)
+      typedef float lds_f4 __attribute__((ext_vector_type(4)));
+      const __attribute__((address_space(3))) lds_f4* seg = (const __attribute__((address_space(3))) lds_f4*)row;
 #pragma unroll
       for (int v = 0; v < (KLEN + 5) / 4; ++v) {
-        const float4 t = ld4(row + 4 * v);
+        const lds_f4 t = __builtin_nontemporal_load(seg + v);
         w[4 * v] = t.x; w[4 * v + 1] = t.y; w[4 * v + 2] = t.z; w[4 * v + 3] = t.w;
       }
 #pragma unroll
@@ -109,13 +113,24 @@ __global__ __launch_bounds__(kBlock) void blur_sep_kernel(const float* __restric
     const int gx = x0 + lx;
     const float* col = tmid + (4 * g) * TW + lx;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    float w0 = col[0], w1 = col[TW], w2 = col[2 * TW];
+    if (KLEN) {                                          // all KLEN + 3 column values in flight at once, taps from registers
+      float w[KLEN + 3];
+#pragma unroll
+      for (int t = 0; t < KLEN + 3; ++t) w[t] = col[t * TW];
+#pragma unroll
+      for (int j = 0; j < KLEN; ++j) {
+        const float k = k1d[j];
+        a0 = __builtin_fmaf(k, w[j], a0); a1 = __builtin_fmaf(k, w[j + 1], a1); a2 = __builtin_fmaf(k, w[j + 2], a2); a3 = __builtin_fmaf(k, w[j + 3], a3);
+      }
+    } else {
+      float w0 = col[0], w1 = col[TW], w2 = col[2 * TW];
 #pragma unroll 8
-    for (int j = 0; j < klen; ++j) {
-      const float w3 = col[(j + 3) * TW];
-      const float k = k1d[j];
-      a0 = __builtin_fmaf(k, w0, a0); a1 = __builtin_fmaf(k, w1, a1); a2 = __builtin_fmaf(k, w2, a2); a3 = __builtin_fmaf(k, w3, a3);
-      w0 = w1; w1 = w2; w2 = w3;
+      for (int j = 0; j < klen; ++j) {
+        const float w3 = col[(j + 3) * TW];
+        const float k = k1d[j];
+        a0 = __builtin_fmaf(k, w0, a0); a1 = __builtin_fmaf(k, w1, a1); a2 = __builtin_fmaf(k, w2, a2); a3 = __builtin_fmaf(k, w3, a3);
+        w0 = w1; w1 = w2; w2 = w3;
+      }
     }
     if (gx >= W) continue;
     const int gy = y0 + 4 * g;

@@ -14,7 +14,7 @@ import sys
 
 
 def load(d):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
