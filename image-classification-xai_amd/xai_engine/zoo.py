@@ -147,6 +147,15 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(3, dim, patch, stride=patch)
 
     def forward(self, x):
+        """Non-overlapping patches: the stride-p p x p convolution IS a GEMM over (C*p*p)-vectors, and is run as one --
+        same weights (`proj.weight` / `proj.bias`, so state dicts interchange with the reference's Conv2d), same sums.
+        MIOpen has no tuned solver for this shape: in immediate mode its backward-data (the gradient with respect to the
+        image, which every IG step needs) falls to a naive kernel at ~7 s per call."""
+        p = self.patch_size[0]
+        B, C, H, W = x.shape
+        if H % p == 0 and W % p == 0:
+            patches = x.reshape(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // p) * (W // p), C * p * p)
+            return nn.functional.linear(patches, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
         return self.proj(x).flatten(2).transpose(1, 2)
 
 
