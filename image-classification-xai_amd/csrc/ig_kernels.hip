@@ -30,6 +30,10 @@ template <> struct Vec<4> {
     return make_float4(v.x, v.y, v.z, v.w);
   }
   static __device__ __forceinline__ void store(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
+  static __device__ __forceinline__ void store_nt(float* p, T v) {
+    const fx4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<fx4*>(p));
+  }
   static __device__ __forceinline__ T splat(float s) { return make_float4(s, s, s, s); }
 };
 template <> struct Vec<1> {
@@ -37,6 +41,7 @@ template <> struct Vec<1> {
   static __device__ __forceinline__ T load(const float* p) { return *p; }
   static __device__ __forceinline__ T load_nt(const float* p) { return __builtin_nontemporal_load(p); }
   static __device__ __forceinline__ void store(float* p, T v) { *p = v; }
+  static __device__ __forceinline__ void store_nt(float* p, T v) { __builtin_nontemporal_store(v, p); }
   static __device__ __forceinline__ T splat(float s) { return s; }
 };
 __device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -52,8 +57,9 @@ __device__ __forceinline__ float vabs(float a) { return fabsf(a); }
 
 // =========================================================================== K1 interpolation
 // grid = (element tiles, step chunks, images).  A lane keeps x and (x-b) of its column in
-// registers and writes `steps_per_chunk` rows; alphas come through the scalar cache.
-template <int W>
+// registers and writes `steps_per_chunk` rows; alphas come through the scalar cache.  NT: non-temporal stores, for
+// outputs that cannot stay cache-resident for the classifier anyway (same policy and evidence as K4, rise_kernels.hip).
+template <int W, bool NT>
 __global__ __launch_bounds__(kBlock) void ig_interp_kernel(const float* __restrict__ x, const float* __restrict__ base,
                                                            float base_scalar, const float* __restrict__ alphas,
                                                            int64_t alpha_img_stride, int n_alpha, int64_t n_elem,
@@ -69,7 +75,10 @@ __global__ __launch_bounds__(kBlock) void ig_interp_kernel(const float* __restri
   const typename V::T dv = vsub(xv, bv);
   const float* al = alphas + img * alpha_img_stride;
   float* o = out + (static_cast<int64_t>(img) * n_alpha + s0) * n_elem + e;
-  for (int s = s0; s < s1; ++s, o += n_elem) V::store(o, vadd(bv, vmul(V::splat(al[s]), dv)));
+  for (int s = s0; s < s1; ++s, o += n_elem) {
+    const typename V::T v = vadd(bv, vmul(V::splat(al[s]), dv));
+    if (NT) V::store_nt(o, v); else V::store(o, v);
+  }
 }
 
 // =========================================================================== Left-IG cutoff
@@ -402,8 +411,9 @@ XAI_EXPORT int xai_ig_interp_f32(const float* x, const float* baseline, float ba
   const bool vec = can_vec4(n_elem, {x, baseline, out});
   const int64_t tiles = xai_ceil_div(n_elem, kBlock * (vec ? 4 : 1));
   int per, chunks;
-  if (static_cast<int64_t>(n_img) * n_alpha * n_elem * 4 >= (int64_t(256) << 20)) {
-    per = n_alpha >= 2 ? 2 : 1;                                   // HBM-sized output: many short streams
+  const bool hbm_sized = static_cast<int64_t>(n_img) * n_alpha * n_elem * 4 >= (int64_t(256) << 20);
+  if (hbm_sized) {
+    per = n_alpha >= 2 ? 2 : 1;                                   // HBM-sized output: many short streams, non-temporal
   } else {                                                        // cache-sized output: just enough workgroups to fill the chip
     const int c0 = static_cast<int>(std::min<int64_t>(n_alpha, std::max<int64_t>(1, xai_ceil_div(2048, tiles * n_img))));
     per = static_cast<int>(xai_ceil_div(n_alpha, c0));
@@ -411,10 +421,11 @@ XAI_EXPORT int xai_ig_interp_f32(const float* x, const float* baseline, float ba
   chunks = static_cast<int>(xai_ceil_div(n_alpha, per));
   XAI_REQUIRE(chunks <= 65535, XAI_E_UNSUPPORTED);
   dim3 grid(static_cast<unsigned>(tiles), chunks, n_img);
-  if (vec)
-    hipLaunchKernelGGL(ig_interp_kernel<4>, grid, dim3(kBlock), 0, st, x, baseline, baseline_scalar, alphas, alpha_img_stride, n_alpha, n_elem, per, out);
-  else
-    hipLaunchKernelGGL(ig_interp_kernel<1>, grid, dim3(kBlock), 0, st, x, baseline, baseline_scalar, alphas, alpha_img_stride, n_alpha, n_elem, per, out);
+#define XAI_INTERP(W, NT) \
+  hipLaunchKernelGGL((ig_interp_kernel<W, NT>), grid, dim3(kBlock), 0, st, x, baseline, baseline_scalar, alphas, alpha_img_stride, n_alpha, n_elem, per, out)
+  if (vec) { if (hbm_sized) XAI_INTERP(4, true); else XAI_INTERP(4, false); }
+  else     { if (hbm_sized) XAI_INTERP(1, true); else XAI_INTERP(1, false); }
+#undef XAI_INTERP
   return xai_launch_status();
 }
 

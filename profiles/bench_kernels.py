@@ -75,7 +75,7 @@ def main():
     start, finish = x[0].contiguous(), torch.zeros_like(x[0])
     sal = torch.rand(1, H * W, device=DEV)
     ms = timeit(lambda: K.rank(sal))
-    rep("rank 50176 keys", 4 * H * W * 8 * 2, ms, "4 passes x (key+idx) r+w, L2-resident; 1 memset + 9 launches")
+    rep("rank 50176 keys", 4 * H * W * 8 * 2, ms, "4 passes x (key+idx) r+w, L2-resident; zero-fill kernel + 9 launches")
     order, rk = K.rank(sal)
     flip = K.flip_steps(rk[0], True, 224)
     buf = torch.empty(224, C, H, W, device=DEV)

@@ -482,6 +482,51 @@ def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
         assert f"rank {r} ok" in o
 
 
+_RCCL_ONE_RANK = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from xai_engine import dist as xd, sweep
+rank, world, dev = xd.init_from_env()                      # backend: nccl (= RCCL), device cuda:0
+assert (rank, world) == (0, 1) and dev.type == "cuda"
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+# the three messages of the sharded paths, with their dtypes and sizes, through RCCL itself (one rank: the values must come back unchanged)
+vec = torch.arange(11, dtype=torch.float64, device=dev) * 0.5          # 88 B: 10 metric sums + count
+dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+assert vec.cpu().tolist() == [0.5 * i for i in range(11)]
+part = torch.rand(224, 224, dtype=torch.float64, device=dev)           # 401 KB: RISE partial map
+keep = part.clone(); dist.all_reduce(part, op=dist.ReduceOp.SUM); assert torch.equal(part, keep)
+acc = torch.rand(1, 3, 224, 224, device=dev)                           # 602 KB: IG step-sharded partial sum
+keep = acc.clone(); dist.all_reduce(acc, op=dist.ReduceOp.SUM); assert torch.equal(acc, keep)
+packed = torch.randint(0, 256, (576016,), dtype=torch.uint8, device=dev)   # the packed mask draw of N = 8000
+keep = packed.clone(); dist.broadcast(packed, src=0); assert torch.equal(packed, keep)
+t = torch.tensor([1.25], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t) == 1.25   # bench.py's max-over-ranks
+dist.barrier()
+total, used = sweep.reduce_counters({k: 1.0 for k in sweep.KEYS}, 3, dev)   # world 1: no collective, same values
+assert used == 3 and all(v == 1.0 for v in total.values())
+dist.destroy_process_group()
+print("rccl one rank ok")
+'''
+
+
+def test_rccl_accepts_the_collectives_of_the_sharded_paths_on_one_rank(tmp_path):
+    """RCCL needs one GPU per rank, so a 1-GPU box cannot run two ranks on it; what it can do is initialise the `nccl`
+    backend with world_size 1 and push the exact messages of the three sharded paths (dtypes, sizes, ops) through RCCL."""
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG
+    script = tmp_path / "rccl1.py"
+    script.write_text(_RCCL_ONE_RANK)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("XAI_DIST_BACKEND", None); env.pop("XAI_FORCE_DEVICE", None)
+    r = subprocess.run([sys.executable, str(script), PKG], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "rccl one rank ok" in r.stdout
+
+
 def _bench(*flags, ranks=1):
     """python bench.py ... as the driver starts it (bench.py relaunches itself under torchrun for --gpus > 1); with two ranks
     both share cuda:0 and talk over gloo.  -> (the parsed JSON line, stdout)"""

@@ -51,6 +51,25 @@ def test_ig_interp_bit_exact(K, shape):
         np.testing.assert_array_equal(got2[i], oig.interpolate(x[i], b[i], al2[i]))
 
 
+def test_ig_interp_full_size_hbm_branch_bit_exact(K):
+    """BASELINE's full size (32 images x 50 steps x 3x224x224 = 963 MB written): the HBM-sized launch plan of K1 (2 step rows
+    per lane, non-temporal stores) against base + alpha * (x - base) evaluated by torch on the device with the same two
+    roundings -- bit for bit, tensor and scalar baselines."""
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn((32, 3, 224, 224), device=DEV, generator=gen)
+    b = torch.randn((32, 3, 224, 224), device=DEV, generator=gen) * 0.3
+    al = torch.linspace(0, 1, 50).to(DEV)
+    got = K.ig_interp(x, b, al)
+    assert got.shape == (32, 50, 3, 224, 224)
+    for i in (0, 13, 31):
+        want = b[i][None] + al.view(-1, 1, 1, 1) * (x[i] - b[i])[None]
+        assert torch.equal(got[i], want)
+    got = K.ig_interp(x, 0.25, al)
+    for i in (5, 31):
+        want = torch.full_like(x[i], 0.25)[None] + al.view(-1, 1, 1, 1) * (x[i] - 0.25)[None]
+        assert torch.equal(got[i], want)
+
+
 # ------------------------------------------------------------------------------ K2
 def test_ig_accum_on_reference_gradients(K):
     """The reference's own per-step gradients in, the reference's IG / Left-IG out."""
