@@ -137,7 +137,7 @@ def run_sweep_workload(args, model, dev, rank, world, prep, miopen_mode, fence, 
     from xai_engine.sweep import sweep_images, get_CNN_attr, KEYS
     methods = [m for m in args.sweep_methods.split(",") if m]
     images = SyntheticImages(args.sweep_images)
-    td = {"models": [model], "img_hw": H, "batch_size": 50, "device": str(dev)}
+    td = {"models": [model], "img_hw": H, "batch_size": 50, "device": str(dev), "device_maps": True}
 
     def one_pass(imgs):
         out = {}

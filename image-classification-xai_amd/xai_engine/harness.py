@@ -119,8 +119,11 @@ def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pe
 
     is_vit = "VIT" in testing_dict["model_name"]                # the reference picks the dispatch table by model name (:577-582)
 
+    # CNN methods + fused sweep: attribution maps stay on the device (no host sync between attribution and sweep)
+    td_attr = dict(testing_dict, device_maps=True) if (fused and not is_vit) else testing_dict
+
     def attr_fn(x, target):
-        return (_sweep.get_VIT_attr if is_vit else _sweep.get_CNN_attr)(x, None, target, testing_dict)
+        return (_sweep.get_VIT_attr if is_vit else _sweep.get_CNN_attr)(x, None, target, td_attr)
 
     identity = _sweep.sweep_identity(attr_func=testing_dict["attr_func"], model_name=testing_dict["model_name"],
                                      image_count=testing_dict["image_count"], files="|".join(c[0] for c in chosen),

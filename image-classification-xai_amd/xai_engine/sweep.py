@@ -33,7 +33,10 @@ VIT_ATTR_FUNCS = ("attn", "grad", "n_rollout", "rollout", "t_attn", "bi_attn", "
 
 def get_CNN_attr(input_tensor, trans_img, target_class, testing_dict):
     """(H,W) float32 numpy saliency map = |sum over channels| of the attribution
-    (reference evaluatePerturbation.py:82-181, the methods on the accelerated path)."""
+    (reference evaluatePerturbation.py:82-181, the methods on the accelerated path).
+    testing_dict["device_maps"] = True (not a reference key): return the same map as a device tensor instead -- no
+    device-to-host copy and, above all, no host sync between the attribution and the perturbation sweep of an image, so
+    `sweep_images` can keep the GPU queue full (the fused sweep takes device maps as they are)."""
     model = testing_dict["models"][0]
     batch_size = testing_dict["batch_size"]
     img_hw = testing_dict["img_hw"]
@@ -65,11 +68,17 @@ def get_CNN_attr(input_tensor, trans_img, target_class, testing_dict):
             cache = testing_dict.setdefault("_captured_gradcam", {})
             if key not in cache:
                 cache[key] = CapturedGradCam(model, model.layer4, x, (img_hw, img_hw))
-            return cache[key](x, target_class)[0].cpu().numpy()
-        return gradcam_saliency(model, model.layer4, x, target_class, (img_hw, img_hw))[0].cpu().numpy()
+            sal = cache[key](x, target_class)[0]
+        else:
+            sal = gradcam_saliency(model, model.layer4, x, target_class, (img_hw, img_hw))[0]
+        return sal if testing_dict.get("device_maps") else sal.cpu().numpy()
     else:
         print("Model-attribution mismatch, please use --help.")
         raise SystemExit
+    if testing_dict.get("device_maps"):
+        # (a + b) + c per pixel, the order NumPy's sum over the leading axis uses: bit-identical to the host expression
+        m = saliency_map.detach()
+        return ((m[0] + m[1]) + m[2]).abs() if m.shape[0] == 3 else m.sum(0).abs()
     return np.abs(np.sum(saliency_map.detach().cpu().numpy(), axis=0))
 
 

@@ -306,6 +306,12 @@ def test_get_CNN_attr_dispatch():
     torch.manual_seed(1)
     sg = get_CNN_attr(x.clone().to(DEV), None, t, dict(td, attr_func="sg"))
     assert sg.shape == (32, 32) and np.isfinite(sg).all()
+    # device_maps: the same maps as device tensors, bit for bit (no host round trip between attribution and sweep)
+    for name in ("grad", "inp_x_grad", "ig", "lig", "idg", "gc"):
+        host = get_CNN_attr(x.clone(), None, t, dict(td, attr_func=name))
+        devm = get_CNN_attr(x.clone(), None, t, dict(td, attr_func=name, device_maps=True))
+        assert torch.is_tensor(devm) and devm.is_cuda and devm.shape == (32, 32) and devm.dtype == torch.float32
+        np.testing.assert_array_equal(devm.cpu().numpy(), host)
     with pytest.raises(SystemExit):
         get_CNN_attr(x, None, t, dict(td, attr_func="nope"))
 
