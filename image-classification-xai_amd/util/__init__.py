@@ -7,3 +7,9 @@ imports of the hot path resolve here, every other `util.*` module resolves to th
 from xai_engine._shim import extend as _extend
 
 __path__ = _extend(__path__, __name__)
+
+import os as _os
+
+if _os.environ.get("XAI_PATCH_CAPTUM") == "1":      # opt-in, see xai_engine.gradcam.patch_captum
+    from xai_engine.gradcam import patch_captum as _patch_captum
+    _patch_captum()

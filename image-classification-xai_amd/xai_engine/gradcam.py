@@ -64,6 +64,30 @@ class LayerGradCam:
         return cam.unsqueeze(1)
 
 
+def patch_captum():
+    """Opt-in ("captum itself is not replaced or monkey-patched unless asked"): make
+    `from captum.attr import LayerGradCam` -- evaluatePerturbation.py:43, the one harness import of the Grad-CAM path that does
+    not go through `util.*` -- resolve to the HIP engine's class.  Only that one name of an installed captum is rebound; every
+    other captum class stays captum's.  Returns the class that was replaced (None if captum is not importable: nothing to do).
+    Asked for either by calling this function before the harness's imports, or by XAI_PATCH_CAPTUM=1 in the environment
+    (honoured when the `util` mirror is imported, i.e. at the harness's first `util` import, :17)."""
+    try:
+        import captum.attr as cattr
+    except ImportError:
+        return None
+    old = getattr(cattr, "LayerGradCam", None)
+    if old is LayerGradCam:
+        return old
+    cattr.LayerGradCam = LayerGradCam
+    try:                                            # captum re-exports the class from its defining module as well
+        import importlib
+        mod = importlib.import_module("captum.attr._core.layer.grad_cam")
+        mod.LayerGradCam = LayerGradCam
+    except ImportError:
+        pass
+    return old
+
+
 def gradcam_saliency(model, layer, inputs, target, out_hw, channels=3):
     """The (B,H,W) map get_CNN_attr produces for "gc": |sum of `channels` copies of the
     up-sampled, ReLU'd cam| (reference evaluatePerturbation.py:147-153,181), fused into the

@@ -163,3 +163,41 @@ def test_mirror_alone_still_imports_and_says_what_is_missing():
     r = _run(ALONE, PKG)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "alone ok" in r.stdout
+
+
+CAPTUM = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[1])          # build first, then the tree holding a (stub) captum
+    import captum.attr
+    theirs = captum.attr.LayerGradCam
+    from util import model_utils                                               # the harness's first util import (:17)
+    from captum.attr import GuidedBackprop, LayerGradCam                       # :43
+    import xai_engine.gradcam as gc
+    if os.environ.get("XAI_PATCH_CAPTUM") == "1":
+        assert LayerGradCam is gc.LayerGradCam and GuidedBackprop.WHO == "captum"
+        assert gc.patch_captum() is gc.LayerGradCam                            # idempotent
+    else:
+        assert LayerGradCam is theirs and LayerGradCam.WHO == "captum"         # not asked: captum untouched
+        assert gc.patch_captum() is theirs
+        from captum.attr import LayerGradCam as again
+        assert again is gc.LayerGradCam
+    print("captum ok")
+""")
+
+
+def test_captum_LayerGradCam_is_rebound_only_when_asked(tmp_path):
+    """evaluatePerturbation.py:43 imports LayerGradCam from captum, the one import of the path outside `util.*`: the overlay is
+    opt-in (XAI_PATCH_CAPTUM=1 or xai_engine.gradcam.patch_captum()) and touches that one name only.  Stub captum in tmp_path."""
+    pkg = tmp_path / "site" / "captum" / "attr"
+    pkg.mkdir(parents=True)
+    (tmp_path / "site" / "captum" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("class LayerGradCam: WHO = 'captum'\nclass GuidedBackprop: WHO = 'captum'\n")
+    for flag in ("0", "1"):
+        env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+        env["XAI_PATCH_CAPTUM"] = flag
+        r = subprocess.run([sys.executable, "-c", CAPTUM, PKG, str(tmp_path / "site")], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "captum ok" in r.stdout
+    # without captum installed the call is a no-op
+    r = _run("import sys; sys.path.insert(0, sys.argv[1]); import xai_engine.gradcam as g; assert g.patch_captum() is None; print('none ok')", PKG)
+    assert r.returncode == 0 and "none ok" in r.stdout, r.stdout + r.stderr
