@@ -567,8 +567,8 @@ def test_bench_contract_line_with_one_and_two_ranks():
         assert rf["bound"] == "hbm" and rf["kernel"] == "xai_ig_accum_f32" and 0 < rf["frac"] < 1 and "traffic_source" in rf
         assert abs(line["value"] - n * 4 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]        # whole-job aggregate
     assert "cpu_baseline" not in two
-    # two ranks on ONE card: the aggregate can only be about what one rank gets alone
-    assert 0.4 <= two["value"] / one["value"] <= 1.6, (one["value"], two["value"])
+    # two ranks on ONE card: the aggregate can only be about what one rank gets alone (one 4-image step each: a loose band)
+    assert 0.25 <= two["value"] / one["value"] <= 2.5, (one["value"], two["value"])
 
 
 def test_bench_sweep_workload_is_strong_scaling_over_one_fixed_list():
