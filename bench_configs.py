@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--fuse-bn-relu", type=int, default=1, help="1 = ResNet-50's eval BN + ReLU (+ add) through the fused HIP kernels "
                     "(xai_engine/prepare.py: fuse_bn_relu, verified per call site); 0 = classifier exactly as given")
     ap.add_argument("--record-db", default=None, help="directory to record a find-db into (exhaustive find: minutes)")
+    ap.add_argument("--deterministic", type=int, default=0, help="1 = torch.backends.cudnn.deterministic: bit-reproducible classifier passes "
+                    "(immediate-mode throughput; the find-db is not used)")
     args = ap.parse_args()
     want = {int(c) for c in args.configs.split(",")}
 
@@ -54,9 +56,10 @@ def main():
         os.makedirs(args.record_db, exist_ok=True)
         os.environ["MIOPEN_USER_DB_PATH"] = args.record_db
         torch.backends.cudnn.benchmark = True
-    elif args.miopen_db:
+    elif args.miopen_db and not args.deterministic:
         from xai_engine.prepare import use_tuned_miopen_db
         torch.backends.cudnn.benchmark = use_tuned_miopen_db(rank)
+    torch.backends.cudnn.deterministic = bool(args.deterministic)
     from xai_engine.zoo import resnet50, vit_base_patch16_224
     from xai_engine.ig import IG, ig_batch
     from xai_engine.gradcam import gradcam_saliency

@@ -508,6 +508,16 @@ def test_full_size_rise_properties(K):
     assert rel_inf(a3.cpu().numpy(), (2 * a2 + a1 * 8000 * 0.5).cpu().numpy()) <= 1e-6      # 2*s+1 itself rounds in fp32
     m = K.rise_apply(g8[:64], sh[:64], cell, torch.ones(1, 224, 224, device=DEV), want_masked=False, want_masks=True)
     assert float(m.min()) >= 0.0 and float(m.max()) <= 1.0
+    # store policy: 240 masks x 3 x 224 x 224 = 144 MB of masked images go out with non-temporal stores, 80 masks (48 MB) with
+    # normal ones -- same arithmetic, so the large launch equals its three thirds bit for bit, and the masks equal the oracle's
+    from oracle import rise as orise
+    img = torch.randn(3, 224, 224, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    big, big_m = K.rise_apply(g8[:240], sh[:240], cell, img, want_masked=True, want_masks=True)
+    for lo in (0, 80, 160):
+        part, part_m = K.rise_apply(g8[lo:lo + 80], sh[lo:lo + 80], cell, img, want_masked=True, want_masks=True)
+        assert torch.equal(big[lo:lo + 80], part) and torch.equal(big_m[lo:lo + 80], part_m)
+    want = orise.masks_from(grid[:4].astype(np.float32), shifts[:4], (224, 224), cell)[:, 0]
+    assert np.abs(big_m[:4].cpu().numpy() - want).max() <= 1e-6
 
 
 # ------------------------------------------------------------------------------ ABI conventions: streams and graphs
