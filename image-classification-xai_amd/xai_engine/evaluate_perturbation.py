@@ -16,12 +16,17 @@ import torch
 from . import dist as xd
 from . import harness
 from .sweep import CNN_ATTR_FUNCS, VIT_ATTR_FUNCS
-from .zoo import resnet50, vit_base_patch16_224
+from .zoo import resnet50, resnet101, resnet152, resnext101_64x4d, vit_base_patch16_224, vit_base_patch32_224
 
 MODELS = {
-    # name: (constructor, batch size of the reference's table :627-677, normalisation, num_patches)
-    "R50": (resnet50, 50, (harness.CNN_MEAN, harness.CNN_STD)),
-    "VIT16": (vit_base_patch16_224, 25, (harness.VIT_MEAN, harness.VIT_STD)),
+    # name: (constructor, batch size, normalisation, num_patches) -- names, batch sizes and patch counts of the reference's
+    # table (evaluatePerturbation.py:627-659); "R50" is this build's extra (BASELINE.json's configurations name ResNet-50)
+    "R50": (resnet50, 50, (harness.CNN_MEAN, harness.CNN_STD), 0),
+    "R101": (resnet101, 50, (harness.CNN_MEAN, harness.CNN_STD), 0),
+    "R152": (resnet152, 50, (harness.CNN_MEAN, harness.CNN_STD), 0),
+    "RNXT": (resnext101_64x4d, 25, (harness.CNN_MEAN, harness.CNN_STD), 0),
+    "VIT16": (vit_base_patch16_224, 25, (harness.VIT_MEAN, harness.VIT_STD), 14),
+    "VIT32": (vit_base_patch32_224, 50, (harness.VIT_MEAN, harness.VIT_STD), 7),
 }
 
 
@@ -29,7 +34,7 @@ def build_parser():
     p = argparse.ArgumentParser("")
     p.add_argument("--image_count", type=int, default=1000, help="How many images to test with.")
     p.add_argument("--model", type=str, default="R50", help="Classifier to use: " + ", ".join(MODELS))
-    p.add_argument("--attr_func", type=str, default="ig", help="attr to use: R50: {" + ", ".join(CNN_ATTR_FUNCS) + "}, VIT16: {" +
+    p.add_argument("--attr_func", type=str, default="ig", help="attr to use: R50/R101/R152/RNXT: {" + ", ".join(CNN_ATTR_FUNCS) + "}, VIT16/VIT32: {" +
                    ", ".join(VIT_ATTR_FUNCS) + "}")
     p.add_argument("--cuda_num", type=int, default=0, help="GPU to use when not launched by torchrun.")
     p.add_argument("--dataset_path", type=str, default="../../../ImageNet", help="The path to your dataset input")
@@ -59,7 +64,7 @@ def main(argv=None):
     if world == 1:
         device = torch.device("cuda", args.cuda_num)
         torch.cuda.set_device(device)
-    ctor, batch_size, norm = MODELS[args.model]
+    ctor, batch_size, norm, num_patches = MODELS[args.model]
     model = ctor()
     if args.weights:
         model.load_state_dict(torch.load(args.weights, map_location="cpu", weights_only=True))
@@ -72,7 +77,7 @@ def main(argv=None):
     testing_dict = {"models": [model, model], "imagenet_dataset": args.dataset_path, "normalize": norm, "img_hw": 224,
                     "batch_size": batch_size, "attr_func": args.attr_func, "model_name": args.model,
                     "image_count": args.image_count, "device": str(device), "class_map_path": args.class_map,
-                    "weights_path": args.weights or ""}
+                    "weights_path": args.weights or "", "num_patches": num_patches}
     total, used, _ = harness.evaluate_perturbation(testing_dict, rank=rank, world=world, fused=not args.eight_runs, out_dir=args.out_dir,
                                                      checkpoint=args.checkpoint)
     if rank == 0:

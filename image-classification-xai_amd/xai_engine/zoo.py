@@ -3,8 +3,9 @@ is no network for checkpoints).  The hot path is model-agnostic: these exist onl
 bench.py can run BASELINE.json's named configurations (ResNet-50, ViT-B/16).
 
 ResNet-50 is the standard v1.5 bottleneck network (stride on the 3x3 conv), the architecture
-behind torchvision.models.resnet50 that the reference harness family uses
-(evaluatePerturbation.py:627-640 instantiates its deeper siblings).  ViT-B/16 follows the
+behind torchvision.models.resnet50; resnet101 / resnet152 / resnext101_64x4d are the deeper siblings the
+reference harness instantiates (evaluatePerturbation.py:627-647: "R101", "R152", "RNXT"), same block with more
+layers / grouped 3x3 convolutions, parameter names as in torchvision so that its state dicts load as they are.  ViT-B/16 follows the
 layout of the reference's hooked model (util/attribution_methods/VIT_LRP/ViT_ig.py:57-253:
 patch 16, dim 768, depth 12, 12 heads, qkv bias, LayerNorm eps 1e-6, class token, learned
 position embedding) including its attention-map / attention-gradient hooks.
@@ -17,13 +18,14 @@ import torch.nn as nn
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        width = int(planes * (base_width / 64.0)) * groups          # ResNeXt: wider, grouped 3x3 (torchvision's rule)
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, groups=groups, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=False)
         self.downsample = downsample
@@ -37,8 +39,9 @@ class Bottleneck(nn.Module):
 
 
 class ResNet(nn.Module):
-    def __init__(self, layers=(3, 4, 6, 3), num_classes=1000, width=64):
+    def __init__(self, layers=(3, 4, 6, 3), num_classes=1000, width=64, groups=1, width_per_group=64):
         super().__init__()
+        self.groups, self.base_width = groups, width_per_group
         self.inplanes = width
         self.conv1 = nn.Conv2d(3, width, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(width)
@@ -58,9 +61,9 @@ class ResNet(nn.Module):
         down = None
         if stride != 1 or self.inplanes != planes * 4:
             down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
-        seq = [Bottleneck(self.inplanes, planes, stride, down)]
+        seq = [Bottleneck(self.inplanes, planes, stride, down, self.groups, self.base_width)]
         self.inplanes = planes * 4
-        seq += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        seq += [Bottleneck(self.inplanes, planes, groups=self.groups, base_width=self.base_width) for _ in range(1, blocks)]
         return nn.Sequential(*seq)
 
     def forward(self, x):
@@ -69,12 +72,32 @@ class ResNet(nn.Module):
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
-def resnet50(seed=0, num_classes=1000, width=64):
+def _frozen_resnet(seed, layers, num_classes, width, groups=1, width_per_group=64):
     torch.manual_seed(seed)
-    m = ResNet((3, 4, 6, 3), num_classes, width).eval()
+    m = ResNet(layers, num_classes, width, groups, width_per_group).eval()
     for p in m.parameters():
         p.requires_grad_(False)
     return m
+
+
+def resnet50(seed=0, num_classes=1000, width=64):
+    return _frozen_resnet(seed, (3, 4, 6, 3), num_classes, width)
+
+
+def resnet101(seed=0, num_classes=1000, width=64):
+    """the reference's "R101" (evaluatePerturbation.py:627-633)"""
+    return _frozen_resnet(seed, (3, 4, 23, 3), num_classes, width)
+
+
+def resnet152(seed=0, num_classes=1000, width=64):
+    """the reference's "R152" (:634-640; its table builds resnet101 and asks for ResNet152 weights -- here the architecture
+    the weights belong to)"""
+    return _frozen_resnet(seed, (3, 8, 36, 3), num_classes, width)
+
+
+def resnext101_64x4d(seed=0, num_classes=1000, width=64):
+    """the reference's "RNXT" (:641-647): 64 groups, 4 channels per group"""
+    return _frozen_resnet(seed, (3, 4, 23, 3), num_classes, width, groups=64, width_per_group=4)
 
 
 # ------------------------------------------------------------------------------ ViT-B/16 with hooks
@@ -196,3 +219,8 @@ def vit_base_patch16_224(seed=0, **kw):
     for p in m.parameters():
         p.requires_grad_(False)
     return m
+
+
+def vit_base_patch32_224(seed=0, **kw):
+    """the reference's "VIT32" (evaluatePerturbation.py:654-659): patch 32, 7 x 7 patches"""
+    return vit_base_patch16_224(seed, patch=32, **kw)

@@ -325,3 +325,29 @@ def test_tolerances_are_tied_to_measured_errors():
     # what is above the bar is exactly what DESIGN.md section 2 explains: one ReLU gate of ig_224 and the finite-difference slopes
     above = sorted({r["name"] for r in golden if r["measured"] > BAR})
     assert above == ["IG/ig_224.npz/ig_tensor_baseline/under_ill_conditioned_gates", "getSlopes/ig_small"], above
+
+
+def test_model_zoo_matches_the_architectures_the_reference_harness_names():
+    """evaluatePerturbation.py:627-659 instantiates torchvision's resnet101 / resnext101_64x4d and timm-layout ViT-B/16, /32; the
+    build's definitions must take their state dicts as they are: same parameter counts (torchvision / timm's published numbers),
+    same number of state-dict entries, same key names."""
+    from xai_engine import zoo
+    from xai_engine.evaluate_perturbation import MODELS
+    want = {"resnet50": (25557032, 320), "resnet101": (44549160, 626), "resnet152": (60192808, 932), "resnext101_64x4d": (83455272, 626),
+            "vit_base_patch16_224": (86567656, 152), "vit_base_patch32_224": (88224232, 152)}
+    for name, (n_params, n_keys) in want.items():
+        m = getattr(zoo, name)()
+        sd = m.state_dict()
+        assert sum(p.numel() for p in m.parameters()) == n_params, name
+        assert len(sd) == n_keys, (name, len(sd))
+    sd = zoo.resnext101_64x4d().state_dict()
+    assert tuple(sd["layer1.0.conv2.weight"].shape) == (256, 4, 3, 3)                 # 64 groups x 4 channels
+    for k in ("conv1.weight", "bn1.running_var", "layer3.22.bn3.num_batches_tracked", "layer4.0.downsample.1.weight", "fc.bias"):
+        assert k in sd, k
+    sd = zoo.vit_base_patch32_224().state_dict()
+    assert tuple(sd["patch_embed.proj.weight"].shape) == (768, 3, 32, 32) and tuple(sd["pos_embed"].shape) == (1, 50, 768)
+    for k in ("cls_token", "blocks.11.attn.qkv.bias", "blocks.0.mlp.fc2.weight", "norm.weight", "head.bias"):
+        assert k in sd, k
+    # the CLI's table: the reference's names, batch sizes and patch counts
+    assert {k: (v[1], v[3]) for k, v in MODELS.items()} == {"R50": (50, 0), "R101": (50, 0), "R152": (50, 0), "RNXT": (25, 0),
+                                                             "VIT16": (25, 14), "VIT32": (50, 7)}

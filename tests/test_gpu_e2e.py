@@ -1053,6 +1053,24 @@ def test_fuse_bn_relu_on_a_torchvision_style_basic_block_network():
         check(f"fuse_bn_relu/basicblock/fork{int(fork)}/input_gradient", gb.cpu().numpy(), ga.cpu().numpy(), 1e-5, "unfused classifier")
 
 
+def test_fuse_bn_relu_on_resnext_and_the_deeper_resnets():
+    """The reference's "RNXT" / "R101" classifiers (evaluatePerturbation.py:627-647), narrow versions: every fused call site
+    verified bit-identical (grouped 3x3 convolutions stay MIOpen's), whole model bit-identical under deterministic solvers."""
+    from xai_engine.prepare import fuse_bn_relu
+    from xai_engine.zoo import resnext101_64x4d, resnet101
+    from xai_engine.ig import IG
+    x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(8)).to(DEV)
+    for ctor in (resnext101_64x4d, resnet101):
+        model = ctor(seed=0, width=16, num_classes=20).to(DEV)
+        _randomise_bn(model, seed=3)
+        fused = fuse_bn_relu(model, verify=x, fork_residual=True)
+        with torch.no_grad():
+            check(f"fuse_bn_relu/{ctor.__name__}/logits", fused(x).cpu().numpy(), model(x).cpu().numpy(), 1e-5, "unfused classifier")
+        t = torch.tensor(3)
+        check(f"fuse_bn_relu/{ctor.__name__}/IG", IG(x[:1], fused, 10, 5, 1, 0, DEV, t).cpu().numpy(), IG(x[:1], model, 10, 5, 1, 0, DEV, t).cpu().numpy(),
+              1e-5, "unfused classifier")
+
+
 def test_cli_runs_resnet50_with_the_fused_classifier(tmp_path, capsys):
     """python -m xai_engine.evaluate_perturbation on a directory of synthetic files, ResNet-50 (seeded random weights), Grad-CAM,
     --fuse_bn_relu: the selection pre-pass and the sweep run through the fused classifier.  What the reference's sanity filter
