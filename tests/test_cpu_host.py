@@ -351,3 +351,23 @@ def test_model_zoo_matches_the_architectures_the_reference_harness_names():
     # the CLI's table: the reference's names, batch sizes and patch counts
     assert {k: (v[1], v[3]) for k, v in MODELS.items()} == {"R50": (50, 0), "R101": (50, 0), "R152": (50, 0), "RNXT": (25, 0),
                                                              "VIT16": (25, 14), "VIT32": (50, 7)}
+
+
+def _build_abi_host(out_path):
+    """gcc -std=c99 examples/abi_host.c against include/xai_hip.h and the in-tree library -> executable path"""
+    lib_dir = os.path.dirname(_lib_path())
+    cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "abi_host.c"), "-L" + lib_dir, "-lxai_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(out_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return str(out_path)
+
+
+def test_the_header_is_plain_c_and_a_c_host_links_against_the_library(tmp_path):
+    """The drop-in boundary is a C ABI: include/xai_hip.h compiles as C99 (no C++, no torch types) and a plain-C host
+    (examples/abi_host.c) links against libxai_hip.so.  Running it needs a GPU: tests/test_gpu_kernels.py does."""
+    exe = _build_abi_host(tmp_path / "abi_host")
+    out = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
+    used = sorted({l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("xai_")})
+    assert used == ["xai_flip_steps_i32", "xai_ig_accum_f32", "xai_perturb_batch_f32", "xai_rank_f32", "xai_rank_workspace_bytes", "xai_strerror", "xai_version"]

@@ -589,6 +589,18 @@ def test_graph_replays_see_a_fresh_zero_fill_every_time(K):
         np.testing.assert_array_equal(order.cpu().numpy(), np.argsort(sal.cpu().numpy(), axis=1, kind="stable"))
 
 
+def test_plain_c_host_drives_the_abi_without_torch(tmp_path):
+    """examples/abi_host.c: a C99 program with hipMalloc'd buffers calls xai_ig_accum_f32 / xai_rank_f32 / xai_flip_steps_i32 /
+    xai_perturb_batch_f32 and checks them against the reference expressions itself -- the C ABI as a cgo / JNI / ctypes binding
+    would see it, on the system's HIP runtime rather than the one the torch wheel bundles."""
+    import subprocess
+    from test_cpu_host import _build_abi_host
+    exe = _build_abi_host(tmp_path / "abi_host")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi host ok" in r.stdout
+
+
 # ------------------------------------------------------------------------------ degenerate and ragged shapes
 def test_edge_shapes(K):
     from oracle import ig as oig, perturb as op, rise as orise
