@@ -7,8 +7,11 @@ import torch
 
 from conftest import rel_inf
 
+import os
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+SCALE = int(os.environ.get("XAI_FUZZ_SCALE", "1"))       # XAI_FUZZ_SCALE=20: a soak run of the same generators (minutes)
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +28,7 @@ def dev(a, dtype=None):
 
 def shapes(seed, n):
     rng = np.random.default_rng(seed)
-    for _ in range(n):
+    for _ in range(n * SCALE):
         yield int(rng.integers(1, 5)), int(rng.integers(1, 70)), int(rng.integers(1, 90)), rng
 
 
@@ -81,7 +84,7 @@ def test_rank_flip_perturb_segment_random_shapes(K):
 def test_softmax_stats_and_blur_random_shapes(K):
     from oracle import perturb as op
     rng = np.random.default_rng(3)
-    for _ in range(10):
+    for _ in range(10 * SCALE):
         B, Kc = int(rng.integers(1, 60)), int(rng.integers(2, 1200))
         z = (rng.standard_normal((B, Kc)) * rng.uniform(0.5, 6)).astype(np.float32)
         t = int(rng.integers(0, Kc))
@@ -106,7 +109,7 @@ def test_gradcam_bilinear_and_maskers_random_shapes(K):
     from oracle import gradcam as ogc
     from oracle import vit_cx as ocx
     rng = np.random.default_rng(5)
-    for _ in range(8):
+    for _ in range(8 * SCALE):
         B, Cc, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 300)), int(rng.integers(1, 15)), int(rng.integers(1, 15))
         act = rng.standard_normal((B, Cc, h, w)).astype(np.float32)
         grad = rng.standard_normal((B, Cc, h, w)).astype(np.float32)
@@ -119,9 +122,15 @@ def test_gradcam_bilinear_and_maskers_random_shapes(K):
         if h * w >= 2:
             fm = rng.standard_normal((Cc, h, w)).astype(np.float32)
             rows = K.up_rownorm(dev(fm), Ho, Wo).cpu().numpy()
-            ref = ocx.norm_matrix(ocx.resize_maps(fm, Ho, Wo).reshape(Cc, Ho * Wo))
+            up_ref = ocx.resize_maps(fm, Ho, Wo).reshape(Cc, Ho * Wo)
+            ref = ocx.norm_matrix(up_ref)
             ok = np.isfinite(ref).all(axis=1)                                                  # constant maps are 0/0 in both
-            assert np.abs(rows[ok] - ref[ok]).max(initial=0.0) <= 4e-6
+            # (v - min) / (max - min): the last-bit differences of the two up-samples are amplified by |v|max / (max - min),
+            # so a nearly flat map is held to 4e-6 times that factor (a 25x soak run found 5.5e-6 on one of 58 000 maps)
+            span = up_ref.max(axis=1) - up_ref.min(axis=1)
+            amp = np.maximum(1.0, np.abs(up_ref).max(axis=1) / np.where(span > 0, span, 1.0))
+            err = np.abs(rows - ref).max(axis=1)
+            assert (err[ok] <= 4e-6 * amp[ok]).all(), (Cc, h, w, Ho, Wo, float(err[ok].max(initial=0.0)))
 
 
 def test_rise_random_geometries(K):
@@ -129,7 +138,7 @@ def test_rise_random_geometries(K):
     keep probabilities and mask counts, against the oracle's scipy up-sampling."""
     from oracle import rise as orise
     rng0 = np.random.default_rng(8)
-    for _ in range(10):
+    for _ in range(10 * SCALE):
         H, W = int(rng0.integers(9, 120)), int(rng0.integers(9, 120))
         s = int(rng0.choice([2, 3, 5, 7, 8, 8, 11]))
         N = int(rng0.integers(1, 40))
