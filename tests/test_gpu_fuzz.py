@@ -156,3 +156,53 @@ def test_rise_random_geometries(K):
         acc = K.rise_accum(g8, sh, dev(scores), cell, H, W, 1.0 / N / p1)
         want = (scores.reshape(-1, 1).astype(np.float64) * want_masks.reshape(N, -1)).sum(0).reshape(H, W) / N / p1
         assert np.abs(acc.cpu().numpy() - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-3), (H, W, s, N)
+
+
+def test_single_run_random_plans():
+    """The five metric classes on random image sizes, step sizes (ragged last steps), batch sizes (remainder batches, batch >
+    steps), modes, tie-free and heavily tied maps, pixel and patch_mask branches, against the oracle driving the same
+    device-resident tiny classifier: every return value at the 1e-5 bar, counts exact."""
+    import importlib
+    from conftest import load_golden
+    from helpers import tiny_from, logits_fn_of
+    from oracle import perturb as op
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    fn = logits_fn_of(model)
+    table = [("MASTestFunctions", "MASMetric", ("ins", "del", "lerf", "morf"), op.mas), ("RISETestFunctions", "RISEMetric", ("ins", "del", "lerf", "morf"), op.rise_metric),
+             ("AICTestFunctions", "AICMetric", ("ins", "del"), op.aic), ("PosNegPertFunctions", "PositiveNegativePerturbation", ("lerf", "morf"), op.pnp),
+             ("MonotonicityTest", "MonotonicityMetric", ("positive", "negative"), op.mono)]
+    rng = np.random.default_rng(11)
+    for case in range(8 * SCALE):
+        H, W = int(rng.integers(4, 41)) * 1, int(rng.integers(4, 41))
+        HW = H * W
+        x = rng.standard_normal((1, 3, H, W)).astype(np.float32)
+        # non-negative maps, as every caller of the metrics passes (|sum over channels|, evaluatePerturbation.py:181): with signed
+        # maps MAS's density = segment sum / total sum divides by a cancelling fp32 sum (a 1500x soak run: total ~ 1e-3 of the
+        # segments, 1.9e-5 between two correct summation orders)
+        sal = np.abs(rng.standard_normal((H, W))).astype(np.float32)
+        if case % 3 == 2:
+            sal = np.round(sal * 2) / 2                                  # many ties: the stable-order rule decides
+        modname, clsname, modes, ofunc = table[int(rng.integers(0, len(table)))]
+        mode = modes[int(rng.integers(0, len(modes)))]
+        cls = getattr(importlib.import_module("util.test_methods." + modname), clsname)
+        pm = None
+        if case % 4 == 3 and H % 2 == 0 and W % 2 == 0:                  # patch branch: 2 x 2 blocks of patches
+            ph, pw = H // 2, W // 2
+            pm = np.arange(4).reshape(2, 2).repeat(ph, 0).repeat(pw, 1)
+        step = int(rng.integers(1, HW + 1)) if pm is None else HW
+        max_bs = int(rng.integers(1, 70))
+        zeros = lambda t: torch.zeros_like(t)                           # noqa: E731
+        res = cls(model, HW, mode, step, zeros).single_run(torch.from_numpy(x), sal.copy(), DEV, patch_mask=None if pm is None else torch.from_numpy(pm),
+                                                             max_batch_size=max_bs)
+        want = ofunc(fn, x, sal, mode, step, np.zeros_like, pm, max_bs)
+        assert len(res) == len(want), (clsname, mode)
+        for i, (r, w) in enumerate(zip(res, want)):
+            tag = (clsname, mode, H, W, step, max_bs, pm is not None, i)
+            if np.ndim(w) == 0 and isinstance(w, (int, np.integer)):
+                assert int(r) == int(w), tag
+            else:
+                r64, w64 = np.asarray(r, np.float64), np.asarray(w, np.float64)
+                assert r64.shape == w64.shape, tag
+                both_nan = np.isnan(r64) & np.isnan(w64)
+                assert np.abs(np.where(both_nan, 0, r64 - w64)).max(initial=0.0) <= 1e-5 * max(1.0, np.abs(np.where(np.isnan(w64), 0, w64)).max(initial=0.0)), tag
