@@ -206,3 +206,46 @@ def test_single_run_random_plans():
                 assert r64.shape == w64.shape, tag
                 both_nan = np.isnan(r64) & np.isnan(w64)
                 assert np.abs(np.where(both_nan, 0, r64 - w64)).max(initial=0.0) <= 1e-5 * max(1.0, np.abs(np.where(np.isnan(w64), 0, w64)).max(initial=0.0)), tag
+
+
+def test_ig_family_random_cases():
+    """IG / Left-IG / IDG / IDGI on random image sizes, step counts, batch sizes (every divisor plan), alpha_star, scalar and
+    tensor baselines, against the oracle driving the same device-resident tiny classifier: 1e-5, and the print-and-return-zeros
+    convention when steps % batch_size != 0."""
+    from conftest import load_golden
+    from helpers import tiny_from
+    from oracle import ig as oig
+    from util.attribution_methods import saliencyMethods as attr
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    rng = np.random.default_rng(21)
+    for case in range(6 * SCALE):
+        H, W = 4 * int(rng.integers(1, 11)), 4 * int(rng.integers(1, 11))          # the tiny net pools to 4 x 4
+        steps = int(rng.choice([4, 6, 10, 12, 20, 30, 50]))
+        divisors = [d for d in range(1, steps + 1) if steps % d == 0]
+        bs = int(rng.choice(divisors))
+        x = rng.standard_normal((1, 3, H, W)).astype(np.float32)
+        base = float(rng.choice([0.0, 0.25, -0.5])) if case % 2 == 0 else (rng.standard_normal((1, 3, H, W)) * 0.3).astype(np.float32)
+        base_t = torch.from_numpy(base) if isinstance(base, np.ndarray) else base
+        with torch.no_grad():
+            t = int(model(torch.from_numpy(x).to(DEV)).argmax(1)[0])
+        which = ("ig", "lig", "idg", "idgi")[case % 4]
+        tag = (which, H, W, steps, bs, isinstance(base, np.ndarray))
+        if which in ("ig", "lig"):
+            a_star = 1 if which == "ig" else float(rng.choice([0.5, 0.9, 0.99]))
+            got = attr.IG(torch.from_numpy(x), model, steps, bs, a_star, base_t, DEV, torch.tensor(t)).cpu().numpy()
+            want = oig.ig(x, model, steps, bs, a_star, base, t)
+        elif which == "idg":
+            if steps < 6:
+                continue                                                             # the slope schedule needs a few steps to be defined
+            got = attr.IDG(torch.from_numpy(x), model, steps, bs, base_t, DEV, torch.tensor(t)).cpu().numpy()
+            want = oig.idg(x, model, steps, bs, base, t)
+        else:
+            got = attr.IDGI(torch.from_numpy(x), model, steps, bs, base_t, DEV, torch.tensor(t)).cpu().numpy()
+            want = oig.idgi(x, model, steps, bs, base, t)
+        if not np.isfinite(want).all():
+            assert np.array_equal(np.isfinite(got), np.isfinite(want)), tag           # degenerate schedules are NaN in both
+            continue
+        assert rel_inf(got, want) <= 1e-5, (tag, rel_inf(got, want))
+    bad = attr.IG(torch.from_numpy(x), model, 10, 3, 1, 0, DEV, torch.tensor(t))
+    assert bad == (0, 0, 0, 0)
