@@ -201,3 +201,78 @@ def test_captum_LayerGradCam_is_rebound_only_when_asked(tmp_path):
     # without captum installed the call is a no-op
     r = _run("import sys; sys.path.insert(0, sys.argv[1]); import xai_engine.gradcam as g; assert g.patch_captum() is None; print('none ok')", PKG)
     assert r.returncode == 0 and "none ok" in r.stdout, r.stdout + r.stderr
+
+
+REAL_TREE = r'''
+import sys, types, importlib, importlib.abc, importlib.machinery
+sys.dont_write_bytecode = True
+BUILD, REF = sys.argv[1], sys.argv[2]
+sys.path.insert(0, REF); sys.path.insert(0, BUILD)
+
+class _Anything(types.ModuleType):
+    """inert placeholder for a third-party module that is not installed: attributes are placeholders, calls return one"""
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        full = self.__name__ + "." + name
+        m = sys.modules.get(full)
+        if m is None:
+            m = _Anything(full); m.__path__ = []
+            sys.modules[full] = m
+        return m
+    def __call__(self, *a, **k):
+        return _Anything(self.__name__ + "()")
+    def __mro_entries__(self, bases):
+        return (object,)
+
+MISSING = ("torchvision", "clip", "captum", "timm", "cv2", "skimage", "ttach", "fast_pytorch_kmeans", "h5py", "ftfy", "kornia")
+class Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path=None, target=None):
+        if name.split(".")[0] in MISSING:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+    def create_module(self, spec):
+        m = _Anything(spec.name); m.__path__ = []
+        return m
+    def exec_module(self, module):
+        pass
+from transformers import CLIPTokenizerFast  # noqa: F401  (installed; must see that torchvision is absent before the placeholders go in)
+sys.meta_path.insert(0, Finder())
+cv = types.ModuleType("cvxopt"); cv.matrix = lambda *a, **k: None
+cv.solvers = types.SimpleNamespace(options={}, qp=None); sys.modules["cvxopt"] = cv
+
+src = open(REF + "/XAI_Survey/evaluations/evaluatePerturbation.py").read().split("\n")
+block = "\n".join(src[:59]).replace("os.sys.path.append(os.path.dirname(os.path.abspath('..')))", "pass")
+ns = {}
+exec(compile(block, "evaluatePerturbation.py[1:59]", "exec"), ns)
+import xai_engine.ig, xai_engine.perturb, xai_engine.vit_attr, xai_engine.vit_cx, xai_engine.tis, xai_engine.smooth
+assert ns["attr"].IG is xai_engine.ig.IG and ns["attr"].smoothGrad is xai_engine.smooth.smoothGrad
+assert ns["MAS"].MASMetric is xai_engine.perturb.MASMetric and ns["PIC"].AICMetric is xai_engine.perturb.AICMetric
+assert ns["MONO"].MonotonicityMetric is xai_engine.perturb.MonotonicityMetric and ns["PNP"].PositiveNegativePerturbation is xai_engine.perturb.PositiveNegativePerturbation
+assert ns["Baselines"] is xai_engine.vit_attr.Baselines and ns["ViT_CX"] is xai_engine.vit_cx.ViT_CX and ns["TIS"] is xai_engine.tis.TIS
+ref_files = {k: getattr(ns[k], "__file__", None) or sys.modules[ns[k].__module__].__file__ for k in
+             ("resnet", "AGI", "GIG_Builder", "XRAI", "MDAFunctions", "limeAttr", "LRP", "mm_interpret", "imgprocess_keepsize", "clip_lrp")}
+for k, f in ref_files.items():
+    assert f.startswith(REF), (k, f)
+    print(f"{k:22s} <- {f[len(REF) + 1:]}")
+print("real tree ok")
+'''
+
+
+def test_the_reference_harness_own_import_block_runs_against_the_mirror(tmp_path):
+    """Where the reference tree is present (this container: /root/reference; not on the GPU box -> skipped): lines 1-59 of
+    XAI_Survey/evaluations/evaluatePerturbation.py, read from the reference and executed as they are with sys.path = [build,
+    reference].  Third-party packages that are not installed (torchvision, clip, captum, timm, cv2, skimage ...) are inert
+    placeholders.  Hot-path names must come from xai_engine, everything else from files under the reference root."""
+    import pytest
+    ref = "/root/reference"
+    if not os.path.isfile(os.path.join(ref, "XAI_Survey", "evaluations", "evaluatePerturbation.py")):
+        pytest.skip("reference tree not present")
+    script = tmp_path / "real_tree.py"
+    script.write_text(REAL_TREE)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    r = subprocess.run([sys.executable, str(script), PKG, ref], capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "real tree ok" in r.stdout
+    for name in ("resnet", "AGI", "LRP", "mm_interpret"):
+        assert name in r.stdout
