@@ -204,7 +204,7 @@ def test_captum_LayerGradCam_is_rebound_only_when_asked(tmp_path):
 
 
 REAL_TREE = r'''
-import sys, types, importlib, importlib.abc, importlib.machinery
+import sys, types, importlib, importlib.abc, importlib.machinery, importlib.util
 sys.dont_write_bytecode = True
 BUILD, REF = sys.argv[1], sys.argv[2]
 sys.path.insert(0, REF); sys.path.insert(0, BUILD)
@@ -240,28 +240,37 @@ sys.meta_path.insert(0, Finder())
 cv = types.ModuleType("cvxopt"); cv.matrix = lambda *a, **k: None
 cv.solvers = types.SimpleNamespace(options={}, qp=None); sys.modules["cvxopt"] = cv
 
-src = open(REF + "/XAI_Survey/evaluations/evaluatePerturbation.py").read().split("\n")
-block = "\n".join(src[:59]).replace("os.sys.path.append(os.path.dirname(os.path.abspath('..')))", "pass")
-ns = {}
-exec(compile(block, "evaluatePerturbation.py[1:59]", "exec"), ns)
+import re
+EVAL = REF + "/XAI_Survey/evaluations"
+sys.path.insert(2, EVAL)                                       # the scripts run from their own directory (`from utils.metrices import *`)
+MISSING_EXTRA = ("matplotlib",) if importlib.util.find_spec("matplotlib") is None else ()
 import xai_engine.ig, xai_engine.perturb, xai_engine.vit_attr, xai_engine.vit_cx, xai_engine.tis, xai_engine.smooth
-assert ns["attr"].IG is xai_engine.ig.IG and ns["attr"].smoothGrad is xai_engine.smooth.smoothGrad
-assert ns["MAS"].MASMetric is xai_engine.perturb.MASMetric and ns["PIC"].AICMetric is xai_engine.perturb.AICMetric
-assert ns["MONO"].MonotonicityMetric is xai_engine.perturb.MonotonicityMetric and ns["PNP"].PositiveNegativePerturbation is xai_engine.perturb.PositiveNegativePerturbation
-assert ns["Baselines"] is xai_engine.vit_attr.Baselines and ns["ViT_CX"] is xai_engine.vit_cx.ViT_CX and ns["TIS"] is xai_engine.tis.TIS
-ref_files = {k: getattr(ns[k], "__file__", None) or sys.modules[ns[k].__module__].__file__ for k in
-             ("resnet", "AGI", "GIG_Builder", "XRAI", "MDAFunctions", "limeAttr", "LRP", "mm_interpret", "imgprocess_keepsize", "clip_lrp")}
-for k, f in ref_files.items():
-    assert f.startswith(REF), (k, f)
-    print(f"{k:22s} <- {f[len(REF) + 1:]}")
+for script in ("evaluatePerturbation.py", "evaluateSanity.py", "evaluateImageNetSeg.py", "qualitativeGeneration.py"):
+    src = open(EVAL + "/" + script).read().split("\n")
+    n = next(i for i, l in enumerate(src) if re.match(r"^(def |class |with open|if __name__)", l))
+    block = "\n".join(src[:n]).replace("os.sys.path.append(os.path.dirname(os.path.abspath('..')))", "pass")
+    ns = {}
+    exec(compile(block, f"{script}[1:{n}]", "exec"), ns)
+    assert ns["attr"].IG is xai_engine.ig.IG and ns["attr"].smoothGrad is xai_engine.smooth.smoothGrad, script
+    assert ns["MAS"].MASMetric is xai_engine.perturb.MASMetric, script
+    if "PIC" in ns:
+        assert ns["PIC"].AICMetric is xai_engine.perturb.AICMetric and ns["MONO"].MonotonicityMetric is xai_engine.perturb.MonotonicityMetric
+        assert ns["PNP"].PositiveNegativePerturbation is xai_engine.perturb.PositiveNegativePerturbation
+    assert ns["Baselines"] is xai_engine.vit_attr.Baselines and ns["ViT_CX"] is xai_engine.vit_cx.ViT_CX and ns["TIS"] is xai_engine.tis.TIS, script
+    names = [k for k in ("resnet", "AGI", "GIG_Builder", "XRAI", "MDAFunctions", "limeAttr", "LRP", "mm_interpret", "imgprocess_keepsize", "clip_lrp", "MASCalibrate",
+                         "attr_to_subplot") if k in ns]
+    for k in names:
+        f = getattr(ns[k], "__file__", None) or sys.modules[ns[k].__module__].__file__
+        assert f.startswith(REF), (script, k, f)
+    print(f"{script}: lines 1-{n} executed; from the reference tree: {', '.join(names)}")
 print("real tree ok")
 '''
 
 
 def test_the_reference_harness_own_import_block_runs_against_the_mirror(tmp_path):
-    """Where the reference tree is present (this container: /root/reference; not on the GPU box -> skipped): lines 1-59 of
-    XAI_Survey/evaluations/evaluatePerturbation.py, read from the reference and executed as they are with sys.path = [build,
-    reference].  Third-party packages that are not installed (torchvision, clip, captum, timm, cv2, skimage ...) are inert
+    """Where the reference tree is present (this container: /root/reference; not on the GPU box -> skipped): the import blocks
+    of all four harness scripts of XAI_Survey/evaluations (evaluatePerturbation.py:1-59, evaluateSanity.py, evaluateImageNetSeg.py,
+    qualitativeGeneration.py), read from the reference and executed as they are with sys.path = [build, reference].  Third-party packages that are not installed (torchvision, clip, captum, timm, cv2, skimage ...) are inert
     placeholders.  Hot-path names must come from xai_engine, everything else from files under the reference root."""
     import pytest
     ref = "/root/reference"
@@ -274,5 +283,5 @@ def test_the_reference_harness_own_import_block_runs_against_the_mirror(tmp_path
     r = subprocess.run([sys.executable, str(script), PKG, ref], capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "real tree ok" in r.stdout
-    for name in ("resnet", "AGI", "LRP", "mm_interpret"):
-        assert name in r.stdout
+    for script in ("evaluatePerturbation.py", "evaluateSanity.py", "evaluateImageNetSeg.py", "qualitativeGeneration.py"):
+        assert script + ": lines 1-" in r.stdout, r.stdout
