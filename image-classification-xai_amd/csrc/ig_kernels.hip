@@ -14,6 +14,8 @@
 // expressions they replace.
 #include "xai_common.h"
 
+#include <hip/hip_ext.h>
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -437,10 +439,13 @@ XAI_EXPORT int xai_ig_cutoff_f32(const float* logits, int n_img, int n_steps, fl
   return xai_launch_status();
 }
 
-XAI_EXPORT int xai_ig_accum_f32(const float* grads, int n_img, int n_steps, const int32_t* n_use_dev, int n_use_host,
-                                const float* step_w1, const float* step_w2, const float* x, const float* baseline,
-                                float baseline_scalar, int C, int64_t hw, float* out_chw, float* out_abs_hw,
-                                xai_stream_t stream) {
+// The launch of K2.  ev0 / ev1 (both or neither): the kernel's own start / stop timestamps are recorded into the caller's
+// events by the dispatch itself (hipExtLaunchKernelGGL) -- a timing without the ~5 us of dispatch latency that two events
+// bracketing a launch include.
+static int ig_accum_impl(const float* grads, int n_img, int n_steps, const int32_t* n_use_dev, int n_use_host,
+                         const float* step_w1, const float* step_w2, const float* x, const float* baseline,
+                         float baseline_scalar, int C, int64_t hw, float* out_chw, float* out_abs_hw,
+                         hipEvent_t ev0, hipEvent_t ev1, xai_stream_t stream) {
   XAI_REQUIRE_PTR(grads); XAI_REQUIRE_PTR(x); XAI_REQUIRE_PTR(out_chw);
   XAI_REQUIRE(n_img > 0 && n_steps > 0 && C > 0 && hw > 0, XAI_E_SHAPE);
   XAI_REQUIRE(n_use_dev != nullptr || (n_use_host >= 1 && n_use_host <= n_steps), XAI_E_SHAPE);
@@ -455,8 +460,10 @@ XAI_EXPORT int xai_ig_accum_f32(const float* grads, int n_img, int n_steps, cons
     const int cus = xai_cu_count();
     const bool big = items >= static_cast<int64_t>(cus) * 2 * 256 * 2;
 #define XAI_STREAM(BLK, IT, SU, CC, WT, GRID) \
-  hipLaunchKernelGGL((ig_accum_stream_kernel<BLK, IT, SU, CC, WT>), dim3(GRID), dim3(BLK), 0, st, grads, n_steps, n_use_dev, n_use_host, \
-                     step_w1, step_w2, x, baseline, baseline_scalar, hw, n_img, out_chw, out_abs_hw)
+  do { if (ev0) hipExtLaunchKernelGGL((ig_accum_stream_kernel<BLK, IT, SU, CC, WT>), dim3(GRID), dim3(BLK), 0, st, ev0, ev1, 0, grads, n_steps, \
+                                      n_use_dev, n_use_host, step_w1, step_w2, x, baseline, baseline_scalar, hw, n_img, out_chw, out_abs_hw); \
+       else hipLaunchKernelGGL((ig_accum_stream_kernel<BLK, IT, SU, CC, WT>), dim3(GRID), dim3(BLK), 0, st, grads, n_steps, n_use_dev, n_use_host, \
+                               step_w1, step_w2, x, baseline, baseline_scalar, hw, n_img, out_chw, out_abs_hw); } while (0)
   // small (cache-resident, latency-bound) problems: few lanes, so each keeps 5 steps x C loads in flight
 #define XAI_STREAM_C(CC, WT) \
   do { if (big) XAI_STREAM(256, 4, 1, CC, WT, static_cast<unsigned>(cus * 2)); \
@@ -469,12 +476,31 @@ XAI_EXPORT int xai_ig_accum_f32(const float* grads, int n_img, int n_steps, cons
   }
   dim3 grid(static_cast<unsigned>(xai_ceil_div(hw, kBlock * (vec ? 4 : 1))), n_img);
 #define XAI_ACCUM(W, WT) \
-  hipLaunchKernelGGL((ig_accum_kernel<W, WT>), grid, dim3(kBlock), 0, st, grads, n_steps, n_use_dev, n_use_host, step_w1, \
-                     step_w2, x, baseline, baseline_scalar, C, hw, out_chw, out_abs_hw)
+  do { if (ev0) hipExtLaunchKernelGGL((ig_accum_kernel<W, WT>), grid, dim3(kBlock), 0, st, ev0, ev1, 0, grads, n_steps, n_use_dev, n_use_host, \
+                                      step_w1, step_w2, x, baseline, baseline_scalar, C, hw, out_chw, out_abs_hw); \
+       else hipLaunchKernelGGL((ig_accum_kernel<W, WT>), grid, dim3(kBlock), 0, st, grads, n_steps, n_use_dev, n_use_host, step_w1, \
+                               step_w2, x, baseline, baseline_scalar, C, hw, out_chw, out_abs_hw); } while (0)
   if (vec) { if (step_w1) XAI_ACCUM(4, true); else XAI_ACCUM(4, false); }
   else     { if (step_w1) XAI_ACCUM(1, true); else XAI_ACCUM(1, false); }
 #undef XAI_ACCUM
   return xai_launch_status();
+}
+
+XAI_EXPORT int xai_ig_accum_f32(const float* grads, int n_img, int n_steps, const int32_t* n_use_dev, int n_use_host,
+                                const float* step_w1, const float* step_w2, const float* x, const float* baseline,
+                                float baseline_scalar, int C, int64_t hw, float* out_chw, float* out_abs_hw,
+                                xai_stream_t stream) {
+  return ig_accum_impl(grads, n_img, n_steps, n_use_dev, n_use_host, step_w1, step_w2, x, baseline, baseline_scalar, C, hw, out_chw,
+                       out_abs_hw, nullptr, nullptr, stream);
+}
+
+XAI_EXPORT int xai_ig_accum_timed_f32(const float* grads, int n_img, int n_steps, const int32_t* n_use_dev, int n_use_host,
+                                      const float* step_w1, const float* step_w2, const float* x, const float* baseline,
+                                      float baseline_scalar, int C, int64_t hw, float* out_chw, float* out_abs_hw,
+                                      void* start_event, void* stop_event, xai_stream_t stream) {
+  XAI_REQUIRE_PTR(start_event); XAI_REQUIRE_PTR(stop_event);
+  return ig_accum_impl(grads, n_img, n_steps, n_use_dev, n_use_host, step_w1, step_w2, x, baseline, baseline_scalar, C, hw, out_chw,
+                       out_abs_hw, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event), stream);
 }
 
 XAI_EXPORT int xai_ig_store_grads_f32(const float* src, float* dst, int64_t n_elem, xai_stream_t stream) {

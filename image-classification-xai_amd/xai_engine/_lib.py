@@ -23,6 +23,7 @@ SIGNATURES = {
     "xai_ig_interp_f32": [_p, _p, _f, _p, _l, _i, _i, _l, _p, _p],
     "xai_ig_cutoff_f32": [_p, _i, _i, _f, _p, _p],
     "xai_ig_accum_f32": [_p, _i, _i, _p, _i, _p, _p, _p, _p, _f, _i, _l, _p, _p, _p],
+    "xai_ig_accum_timed_f32": [_p, _i, _i, _p, _i, _p, _p, _p, _p, _f, _i, _l, _p, _p, _p, _p, _p],
     "xai_ig_store_grads_f32": [_p, _p, _l, _p],
     "xai_ig_accum_add_f32": [_p, _i, _p, _l, _p],
     "xai_ig_finish_f32": [_p, _i, _i, _p, _p, _f, _i, _l, _p, _p, _p],

@@ -185,8 +185,8 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
     step gradients land in one [B][steps][C][H][W] buffer that a single accumulation launch
     reduces (per-image Left-IG cutoffs are computed on the device, no host sync).
     Returns (B,C,H,W) [and the (B,H,W) |sum_c| map the metrics consume].
-    `event_sink`: optional list that receives a (start, end) torch.cuda.Event pair bracketing
-    the accumulation kernel (used by bench.py for the roofline figure)."""
+    `event_sink`: optional list that receives (start, end, kernel_start, kernel_stop) torch.cuda.Events of the
+    accumulation launch: a pair bracketing it and a pair stamped by the dispatch itself (used by bench.py for the roofline figure)."""
     if not x.is_cuda:
         raise XaiHipError("ig_batch needs its input on a HIP device")
     x = x.float().contiguous()
@@ -214,10 +214,12 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
     n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)
     if event_sink is None:
         return K.ig_accum(grads_buffer, x, base, n_use=n_use, want_abs=want_abs)
-    # bench.py: HIP events around the accumulation launch, on the stream it is launched on
+    # bench.py: HIP events for the accumulation launch, on the stream it is launched on -- a pair bracketing the launch
+    # (includes the dispatch latency) and a pair the dispatch itself stamps with the kernel's start / stop
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record(torch.cuda.current_stream(dev))
-    out = K.ig_accum(grads_buffer, x, base, n_use=n_use, want_abs=want_abs)
+    out = K.ig_accum(grads_buffer, x, base, n_use=n_use, want_abs=want_abs, timing_events=(k0, k1))
     t1.record(torch.cuda.current_stream(dev))
-    event_sink.append((t0, t1))
+    event_sink.append((t0, t1, k0, k1))
     return out

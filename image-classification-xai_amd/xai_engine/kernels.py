@@ -78,9 +78,11 @@ def ig_cutoff(logits, alpha_star):
     return n_use
 
 
-def ig_accum(grads, x, baseline, n_use=None, w1=None, w2=None, want_abs=False):
+def ig_accum(grads, x, baseline, n_use=None, w1=None, w2=None, want_abs=False, timing_events=None):
     """grads (n_img, n_steps, C, H, W); x (n_img, C, H, W) -> out (n_img, C, H, W)[, abs (n_img, H, W)].
-    n_use: None (all steps), int, or int32 device tensor (n_img,)."""
+    n_use: None (all steps), int, or int32 device tensor (n_img,).
+    timing_events: optional (start, stop) pair of torch.cuda.Event(enable_timing=True): the kernel's own start / stop
+    timestamps are recorded into them by the dispatch (xai_ig_accum_timed_f32), start.elapsed_time(stop) is the kernel time."""
     _need(grads, F32, "grads"); _need(x, F32, "x")
     n_img, n_steps, Cc = grads.shape[0], grads.shape[1], grads.shape[2]
     hw = grads[0, 0, 0].numel()
@@ -101,8 +103,16 @@ def ig_accum(grads, x, baseline, n_use=None, w1=None, w2=None, want_abs=False):
                 raise ValueError(f"{nm} must be (n_img, n_steps)")
     out = torch.empty((n_img,) + tuple(grads.shape[2:]), dtype=F32, device=x.device)
     out_abs = torch.empty((n_img,) + tuple(grads.shape[3:]), dtype=F32, device=x.device) if want_abs else None
-    _call("xai_ig_accum_f32", x.device, _ptr(grads), n_img, n_steps, _ptr(n_dev), n_host, _ptr(w1), _ptr(w2), _ptr(x), _ptr(b), bs,
-          Cc, hw, _ptr(out), _ptr(out_abs))
+    if timing_events is None:
+        _call("xai_ig_accum_f32", x.device, _ptr(grads), n_img, n_steps, _ptr(n_dev), n_host, _ptr(w1), _ptr(w2), _ptr(x), _ptr(b), bs,
+              Cc, hw, _ptr(out), _ptr(out_abs))
+    else:
+        e0, e1 = timing_events
+        stream = torch.cuda.current_stream(x.device)
+        for e in (e0, e1):                         # torch creates the hipEvent_t on the first record; the dispatch re-records it
+            e.record(stream)
+        _call("xai_ig_accum_timed_f32", x.device, _ptr(grads), n_img, n_steps, _ptr(n_dev), n_host, _ptr(w1), _ptr(w2), _ptr(x), _ptr(b),
+              bs, Cc, hw, _ptr(out), _ptr(out_abs), e0.cuda_event, e1.cuda_event)
     return (out, out_abs) if want_abs else out
 
 

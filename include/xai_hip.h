@@ -73,6 +73,16 @@ int xai_ig_accum_f32(const float* grads, int n_img, int n_steps, const int32_t* 
                      const float* x, const float* baseline, float baseline_scalar, int C,
                      int64_t hw, float* out_chw, float* out_abs_hw, xai_stream_t stream);
 
+/* K2, the same launch (saliencyMethods.py:53,67,70), with the kernel's OWN start / stop timestamps recorded into two
+ * caller-owned hipEvent_t (created with timing enabled) by the dispatch itself (hipExtLaunchKernel): hipEventElapsedTime of
+ * the pair is the kernel's duration, without the dispatch latency that two events bracketing a launch include.  Used by
+ * bench.py for roofline.achieved.  start_event / stop_event : hipEvent_t, both required */
+int xai_ig_accum_timed_f32(const float* grads, int n_img, int n_steps, const int32_t* n_use_dev,
+                           int n_use_host, const float* step_w1, const float* step_w2,
+                           const float* x, const float* baseline, float baseline_scalar, int C,
+                           int64_t hw, float* out_chw, float* out_abs_hw, void* start_event,
+                           void* stop_event, xai_stream_t stream);
+
 /* dst[e] = src[e] with non-temporal stores: files one classifier pass's step gradients into
  * the [n_img][n_steps][C][hw] buffer without leaving dirty lines in the Infinity Cache
  * replaces  `gradients[start:end] = ...` at saliencyMethods.py:46 */

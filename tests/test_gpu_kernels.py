@@ -161,6 +161,25 @@ def test_ig_accum_linearity_full_size(K):
         assert rel_inf(a4[i].cpu().numpy(), want.cpu().numpy()) <= 2e-6
 
 
+def test_ig_accum_kernel_stamped_events(K):
+    """xai_ig_accum_timed_f32: same result as the plain launch; the two events carry the kernel's own start / stop, so their
+    elapsed time is positive and not longer than a pair of events bracketing the same launch."""
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    g = torch.randn((8, 50, 3, 224, 224), device=DEV, generator=gen)
+    x = torch.randn((8, 3, 224, 224), device=DEV, generator=gen)
+    want, want_abs = K.ig_accum(g, x, 0.25, want_abs=True)
+    for _ in range(3):
+        b0, b1, k0, k1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        b0.record()
+        got, got_abs = K.ig_accum(g, x, 0.25, want_abs=True, timing_events=(k0, k1))
+        b1.record()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(got_abs, want_abs)
+        kernel_ms, bracket_ms = k0.elapsed_time(k1), b0.elapsed_time(b1)
+        assert 0.0 < kernel_ms <= bracket_ms, (kernel_ms, bracket_ms)
+        assert kernel_ms >= 240e6 / 8e12 * 1e3                      # 240 MB cannot move faster than the HBM peak: >= 0.03 ms
+
+
 def test_idgi_kernels(K):
     g = load_golden("ig_small.npz")
     grads = dev(g["gradients"])
