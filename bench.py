@@ -267,6 +267,9 @@ def main():
         return ig_batch(x, net if net is not None else model, targets, steps=STEPS_IG, alpha_star=1, baseline=0,
                         images_per_pass=args.images_per_pass, want_abs=True, grads_buffer=grads, event_sink=sink)
 
+    if tuned and args.images_per_pass != 2:
+        log("NOTE: the shipped find-db holds the shapes of --images-per-pass 2 only; for other batch shapes MIOpen's find mode searches "
+            "first (minutes per new shape on a fresh box) -- pass --miopen-db 0 for immediate mode")
     log(f"model + inputs ready on {dev}; warmup x{args.warmup}")
     for _ in range(args.warmup):
         step()
