@@ -311,3 +311,27 @@ def test_kmeans_restatement_recovers_separated_clusters():
     got = otis.kmeans_centroids(pts, 5, rng=np.random.RandomState(11))
     d = np.abs(got[:, None] - centres[None]).max(-1)            # every true centre is found by some centroid or merged
     assert (d.min(0) < 0.1).sum() >= 3
+
+
+def test_config1_gradcam_resnet50_on_the_cpu_reference_path():
+    """BASELINE.json configs[0]: "Grad-CAM on ResNet-50, single 224x224 image, CPU reference path (plumbing, no GPU)".
+    The oracle's Grad-CAM (captum's published arithmetic, cross-checked against the reference-owned CAM code by cam.npz) on
+    the full-size ResNet-50 with seeded random weights, on the host: shapes, the ReLU, the channel-weight identity
+    cam = sum_c mean_hw(grad_c) * act_c, and the 3-channel |.| map the harness turns it into (evaluatePerturbation.py:147-153,181)."""
+    from xai_engine.zoo import resnet50
+    torch.set_num_threads(4)
+    model = resnet50(seed=0)
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        t = int(model(x).argmax(1)[0])
+    act, grad = ogc.layer_act_and_grad(model, model.layer4, x, t)
+    assert act.shape == grad.shape == (1, 2048, 7, 7)
+    cam = ogc.cam_reduce(act, grad, relu=True)
+    raw = ogc.cam_reduce(act, grad, relu=False)
+    assert cam.shape == (1, 7, 7) and (cam >= 0).all() and np.array_equal(cam, np.maximum(raw, 0))
+    w = grad.astype(np.float64).mean(axis=(2, 3), keepdims=True)
+    assert rel_inf(raw, (w * act.astype(np.float64)).sum(1)) <= TOL
+    sal = ogc.gradcam_saliency(act, grad, 224, 224)
+    assert sal.shape == (1, 224, 224) and sal.dtype == np.float32 and (sal >= 0).all()
+    up = torch.nn.functional.interpolate(torch.from_numpy(cam)[None], size=(224, 224), mode="bilinear", align_corners=False)[0].numpy()
+    assert rel_inf(sal, 3 * up) <= TOL                                         # |cam_up + cam_up + cam_up|
