@@ -47,6 +47,9 @@ def build_parser():
                    "GEMMs: run-to-run noise of ~1e-6 on probabilities, profiles/r02_resnet_determinism_*.json).  Default: "
                    "torch.backends.cudnn.deterministic = True -- bit-reproducible sweeps, fused flow == eight-run flow exactly, at the "
                    "throughput of MIOpen's immediate mode")
+    p.add_argument("--batch_size", type=int, default=None, help="images per classifier pass in the metrics (`max_batch_size`); default: the "
+                   "reference's value for the model (50 / 25).  Larger batches are faster (ResNet-50: 98 ms per image-sweep at 50, 91 at 112, "
+                   "88 at 225) and move the ten numbers by <= 3e-6 (profiles/r02_exp_sweep_batch.txt)")
     p.add_argument("--out_dir", type=str, default="pert_test_results")
     p.add_argument("--checkpoint", type=str, default=None, help="path prefix for per-rank resume files (the reference loses a crashed run)")
     return p
@@ -65,6 +68,7 @@ def main(argv=None):
         device = torch.device("cuda", args.cuda_num)
         torch.cuda.set_device(device)
     ctor, batch_size, norm, num_patches = MODELS[args.model]
+    batch_size = args.batch_size or batch_size
     model = ctor()
     if args.weights:
         model.load_state_dict(torch.load(args.weights, map_location="cpu", weights_only=True))
