@@ -371,3 +371,29 @@ def test_the_header_is_plain_c_and_a_c_host_links_against_the_library(tmp_path):
     out = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
     used = sorted({l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("xai_")})
     assert used == ["xai_flip_steps_i32", "xai_ig_accum_f32", "xai_perturb_batch_f32", "xai_rank_f32", "xai_rank_workspace_bytes", "xai_strerror", "xai_version"]
+
+
+def test_class_quota_replays_the_reference_loop_order():
+    """harness.ClassQuota (the order-dependent tail of the selection pre-pass) against the reference loop written out
+    (evaluatePerturbation.py:520-576: stop at image_count, RGB filter, sanity filter, ceil(count / classes) per class)."""
+    from xai_engine.harness import ClassQuota
+    rng = np.random.default_rng(4)
+    for count, n_cls in ((7, 3), (10, 10), (5, 1000), (1000, 1000), (12, 5)):
+        verdicts = [(f"f{i:04d}", bool(rng.random() < 0.9), bool(rng.random() < 0.6), int(rng.integers(0, n_cls))) for i in range(400)]
+        q = ClassQuota(count, n_cls)
+        for v in verdicts:
+            q.offer(*v)
+        per_class = int(np.ceil(count / n_cls))
+        used, want = [0] * n_cls, []
+        for name, rgb, sane, t in verdicts:
+            if len(want) == count:
+                break
+            if not rgb:
+                continue
+            if not sane:
+                continue
+            if used[t] == per_class:
+                continue
+            used[t] += 1
+            want.append((name, t))
+        assert q.chosen == want and q.full == (len(want) == count)

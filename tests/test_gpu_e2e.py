@@ -458,22 +458,43 @@ for a_star in (1, 0.9):
     got = xd.ig_step_sharded(xi, m2, 50, a_star, 0, dev, t)
     want = IG(xi, m2, 50, 25, a_star, 0, dev, t)
     assert rel_inf(got.cpu().numpy(), want.cpu().numpy()) <= 1e-5, (a_star, rel_inf(got.cpu().numpy(), want.cpu().numpy()))
+# (4) the harness's selection pre-pass, sharded: every rank ends with the list a single process selects
+from xai_engine import harness
+root = sys.argv[3]
+bitmap = np.ones(64, dtype=np.int64); bitmap[1] = 0
+td = {"models": [model, model], "imagenet_dataset": root, "img_hw": 32, "image_count": 5, "device": str(dev), "num_classes": 10}
+mine = harness.select_images(td, bitmap, rank=rank, world=world, chunk_per_rank=3)
+names_l, lazy_imgs, classes_l = harness.select_images(td, bitmap, rank=rank, world=world, chunk_per_rank=2, lazy=True)
+alone = harness.select_images(td, bitmap)                          # world = 1: no collective
+assert [c[0] for c in mine] == [c[0] for c in alone] == names_l and [c[2] for c in mine] == [c[2] for c in alone] == classes_l
+assert len(alone) >= 2 and len(lazy_imgs) == len(alone) and torch.equal(lazy_imgs[1], alone[1][1]) and torch.equal(mine[0][1], alone[0][1])
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
 
 
 def test_two_ranks_share_one_gpu_over_gloo(tmp_path):
-    """The three sharding modes (images, RISE masks, IG steps) with world_size 2: both ranks use cuda:0 and
-    reduce through gloo, so the real device data path runs on a 1-GPU box (RCCL itself needs 2 GPUs)."""
+    """The three sharding modes (images, RISE masks, IG steps) and the sharded selection pre-pass with world_size 2: both ranks
+    use cuda:0 and reduce through gloo, so the real device data path runs on a 1-GPU box (RCCL itself needs 2 GPUs)."""
     import os
     import subprocess
     import sys
     from conftest import ROOT, PKG
     script = tmp_path / "worker.py"
     script.write_text(_TWO_RANK_WORKER)
+    from PIL import Image
+    val = tmp_path / "val"
+    val.mkdir()
+    rng = np.random.default_rng(5)
+    for i in range(1, 41):                                                   # the files of test_evaluate_perturbation_on_a_directory
+        blocks = rng.integers(0, 256, (4, 4, 3), dtype=np.uint8)
+        arr = np.kron(blocks, np.ones((12, 16, 1), dtype=np.uint8))
+        arr = np.clip(arr.astype(np.int32) + rng.integers(-40, 40, arr.shape), 0, 255).astype(np.uint8)
+        if i == 3:
+            arr = arr[:, :, 0]
+        Image.fromarray(arr).save(val / f"ILSVRC2012_val_{i:08d}.JPEG", format="PNG")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, str(script), PKG, ROOT], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+    procs = [subprocess.Popen([sys.executable, str(script), PKG, ROOT, str(val)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = []
     try:
