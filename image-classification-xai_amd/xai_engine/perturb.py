@@ -75,7 +75,7 @@ class _PerturbationMetric:
 
     # ---- the shared device pipeline ------------------------------------------------------
     def _run(self, img_tensor, saliency_map, device, patch_mask, max_batch_size, clip_info=None, want_density=False,
-             want_embeddings=False):
+             want_embeddings=False, given_order=None):
         dev = hip_device(device)
         n_steps, step_size, batches = curves.step_plan(self.HW, self.step_size, max_batch_size, patch_mask, self.ALWAYS_LEFTOVER)
         if patch_mask is not None:
@@ -110,7 +110,32 @@ class _PerturbationMetric:
         # pixel order -> flip step per pixel
         seg = total = None
         salient_order = None
-        if patch_mask is None:
+        if given_order is not None:
+            # caller-supplied flip order (keyword-only `salient_order=` of single_run; not a reference argument): the pixel --
+            # or, with patch_mask, patch -- indices in the order they flip.  The reference ranks with NumPy's default, unstable
+            # argsort, so on tied maps (ReLU'd Grad-CAM) its order is machine-dependent; handing that order in reproduces its
+            # curves exactly, where this build's own rule is the stable sort.
+            go = np.ascontiguousarray(np.asarray(given_order).reshape(-1), dtype=np.int64)
+            n_units = self.HW if patch_mask is None else n_steps
+            if go.shape[0] != n_units or not np.array_equal(np.sort(go), np.arange(n_units)):
+                raise ValueError(f"salient_order must be a permutation of range({n_units})")
+            salient_order = go.reshape(1, -1) if patch_mask is None else go
+            if patch_mask is None:
+                flip_np = np.empty(self.HW, dtype=np.int32)
+                flip_np[go] = (np.arange(self.HW) // step_size).astype(np.int32)
+                flip = torch.from_numpy(flip_np).to(dev)
+                if want_density:
+                    sal = torch.as_tensor(np.ascontiguousarray(saliency_map, dtype=np.float32)).reshape(1, self.HW).to(dev)
+                    seg, total = K.segment_sums(sal[0], torch.from_numpy(go.astype(np.int32)).to(dev), False, step_size, n_steps)
+            else:
+                pm = np.asarray(patch_mask.cpu() if hasattr(patch_mask, "cpu") else patch_mask).reshape(-1)
+                step_of_patch = np.empty(n_steps, dtype=np.int32)
+                step_of_patch[go] = np.arange(n_steps, dtype=np.int32)
+                flip_np = step_of_patch[pm].astype(np.int32)
+                flip = torch.from_numpy(flip_np).to(dev)
+                if want_density:
+                    seg, total = curves.patch_density_sums(saliency_map, flip_np, self.HW, n_steps)
+        elif patch_mask is None:
             sal = torch.as_tensor(np.ascontiguousarray(saliency_map, dtype=np.float32)).reshape(1, self.HW).to(dev)
             order, rk = K.rank(sal)
             flip = K.flip_steps(rk[0], self._descending(), step_size)
@@ -159,13 +184,13 @@ class MASMetric(_PerturbationMetric):
     MODES = ('del', 'ins', 'lerf', 'morf')
 
     def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, special_version=False,
-                   return_embeddings=False, CLIP_test_info=None):
+                   return_embeddings=False, CLIP_test_info=None, *, salient_order=None):
         if special_version:
             raise NotImplementedError("special_version (cvxopt QP smoothing of the curve) is outside the accelerated path")
         if return_embeddings and CLIP_test_info is not None:
             raise NotImplementedError("return_embeddings reads model.blocks[i].get_block_out(): hooked ViT classifiers only, as in the reference")
         r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info, want_density=True,
-                      want_embeddings=return_embeddings)
+                      want_embeddings=return_embeddings, given_order=salient_order)
         if return_embeddings:
             return self._embeddings_tuple(r)
         if CLIP_test_info is not None:
@@ -179,8 +204,10 @@ class RISEMetric(_PerturbationMetric):
     """reference util/test_methods/RISETestFunctions.py:34-237"""
     MODES = ('del', 'ins', 'morf', 'lerf')
 
-    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, return_embeddings=False):
-        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, want_embeddings=return_embeddings)
+    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, return_embeddings=False, *,
+                   salient_order=None):
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, want_embeddings=return_embeddings,
+                      given_order=salient_order)
         if return_embeddings:
             return self._embeddings_tuple(r)
         norm = curves.monotone_normalise(r["response"], r["baseline_pred"], r["original_pred"], falling=(self.mode != 'ins'))
@@ -192,8 +219,8 @@ class AICMetric(_PerturbationMetric):
     MODES = ('del', 'ins')
 
     def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, decision_flip=False,
-                   CLIP_test_info=None):
-        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info)
+                   CLIP_test_info=None, *, salient_order=None):
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info, given_order=salient_order)
         response = (r["argmax"] == r["target"]).astype(np.float64)
         original_pred = 1
         baseline_pred = int(r["baseline_class"] == r["target"])
@@ -210,8 +237,9 @@ class PositiveNegativePerturbation(_PerturbationMetric):
     """reference util/test_methods/PosNegPertFunctions.py:14-175: returns the RAW response."""
     MODES = ('lerf', 'morf')
 
-    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, CLIP_test_info=None):
-        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info)
+    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, CLIP_test_info=None, *,
+                   salient_order=None):
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info, given_order=salient_order)
         return r["n_steps"] + 1, r["response"]
 
 
@@ -223,8 +251,9 @@ class MonotonicityMetric(_PerturbationMetric):
     def _descending(self):
         return True
 
-    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, CLIP_test_info=None):
-        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info)
+    def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, CLIP_test_info=None, *,
+                   salient_order=None):
+        r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info, given_order=salient_order)
         n1 = r["n_steps"] + 1
         ramp = np.linspace(1, 0, n1) if self.mode == "negative" else np.linspace(0, 1, n1)
         return r["response"], spearmanr(ramp, r["response"]).correlation

@@ -101,9 +101,17 @@ class Plan:
             self.batches.append(left)
 
 
-def flip_groups(sal, HW, plan, patch_mask, descending):
+def flip_groups(sal, HW, plan, patch_mask, descending, order=None):
     """List of pixel-index arrays, one per step, in the order they switch from `start`
-    to `finish` [MASTestFunctions.py:207-223,251-253]."""
+    to `finish` [MASTestFunctions.py:207-223,251-253].  `order`: the flip order to use instead of the stable sort -- the
+    pixel (or patch) indices, first flipped first -- e.g. the order the reference's unstable argsort gave on a tied map."""
+    if order is not None:
+        order = np.asarray(order).reshape(-1)
+        if patch_mask is None:
+            s = plan.step_size
+            return [order[i * s:(i + 1) * s] for i in range(plan.n_steps)], order
+        pm = np.asarray(patch_mask).reshape(-1)
+        return [np.nonzero(pm == order[i])[0] for i in range(plan.n_steps)], order
     if patch_mask is None:
         order = pixel_order(sal, HW, descending)
         s = plan.step_size
@@ -161,7 +169,7 @@ def _probe(logits_fn, img):
 
 
 # ------------------------------------------------------------------ the five metrics
-def mas(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50):
+def mas(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50, order=None):
     """MASMetric.single_run (special_version=False, no CLIP) [MASTestFunctions.py:72-385].
     Returns (n_steps+1, corrected_scores, entropy, density_response, normalized_response)."""
     assert mode in ("del", "ins", "lerf", "morf")
@@ -184,7 +192,7 @@ def mas(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max
         start, finish = img, sub
         response[0], ent[0] = orig, entropy_bits(p_orig)
 
-    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=(mode != "lerf"))
+    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=(mode != "lerf"), order=order)
     logits, _ = run_steps(logits_fn, start, finish, groups, plan)
     p = softmax_rows(logits)
     response[1:] = p[:, target]
@@ -210,7 +218,7 @@ def mas(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max
     return n + 1, corr, ent, dens, norm
 
 
-def rise_metric(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50):
+def rise_metric(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50, order=None):
     """RISEMetric.single_run [RISETestFunctions.py:51-237] -> (n_steps+1, entropy, normalized)."""
     assert mode in ("del", "ins", "morf", "lerf")
     HW = img.shape[-1] * img.shape[-2]
@@ -229,7 +237,7 @@ def rise_metric(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=N
     else:
         start, finish = img, sub
         response[0], ent[0] = orig, entropy_bits(p_orig)
-    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=(mode != "lerf"))
+    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=(mode != "lerf"), order=order)
     logits, _ = run_steps(logits_fn, start, finish, groups, plan)
     p = softmax_rows(logits)
     response[1:] = p[:, target]
@@ -237,7 +245,7 @@ def rise_metric(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=N
     return n + 1, ent, monotone(response, base, orig, falling=(mode != "ins"))
 
 
-def aic(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50,
+def aic(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50, order=None,
         decision_flip=False):
     """AICMetric.single_run [AICTestFunctions.py:51-225]: the statistic is argmax == target."""
     assert mode in ("del", "ins")
@@ -255,7 +263,7 @@ def aic(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max
     else:
         start, finish = img, sub
         response[0] = orig
-    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=True)
+    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=True, order=order)
     logits, _ = run_steps(logits_fn, start, finish, groups, plan)
     response[1:] = (np.argmax(logits, axis=1) == target) * 1
     if decision_flip:
@@ -265,7 +273,7 @@ def aic(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max
         return n + 1, monotone(response, base, orig, falling=(mode == "del"))
 
 
-def pnp(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50):
+def pnp(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50, order=None):
     """PositiveNegativePerturbation.single_run [PosNegPertFunctions.py:31-175]: RAW response."""
     assert mode in ("lerf", "morf")
     HW = img.shape[-1] * img.shape[-2]
@@ -278,13 +286,13 @@ def pnp(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max
     sub = np.asarray(substrate_fn(img), dtype=F32)
     logits_fn(sub)                                          # baseline probe, value unused in the return
     # lerf = the descending order flipped once more [PosNegPertFunctions.py:115-119]
-    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=(mode == "morf"))
+    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=(mode == "morf"), order=order)
     logits, _ = run_steps(logits_fn, img, sub, groups, plan)
     response[1:] = softmax_rows(logits)[:, target]
     return n + 1, response
 
 
-def mono(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50):
+def mono(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50, order=None):
     """MonotonicityMetric.single_run [MonotonicityTest.py:51-213] -> (raw response, spearman)."""
     assert mode in ("positive", "negative")
     HW = img.shape[-1] * img.shape[-2]
@@ -301,7 +309,7 @@ def mono(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, ma
     else:
         start, finish = sub, img
         response[0] = float(p_sub[target])
-    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=True)
+    groups, _ = flip_groups(sal, HW, plan, patch_mask, descending=True, order=order)
     logits, _ = run_steps(logits_fn, start, finish, groups, plan)
     response[1:] = softmax_rows(logits)[:, target]
     ramp = np.linspace(1, 0, n + 1) if mode == "negative" else np.linspace(0, 1, n + 1)

@@ -15,6 +15,8 @@ What is pinned (reference file:line in brackets):
   perturb_small.npz           32x32 / step 32: salient order, every perturbed image, all
   perturb_patch.npz           five metric classes' return tuples (+ patch_mask branch)
   perturb_224.npz             224x224 / step 224 with per-step image checksums
+  perturb_ties.npz            a heavily tied map (ReLU'd, quantised): return tuples + the pixel order the reference's unstable
+                              argsort produced here, for the caller-supplied-order path (SURVEY 7 "hard parts": tie order)
                               [MASTestFunctions.py:72-385, RISETestFunctions.py:51-237,
                                AICTestFunctions.py:51-225, PosNegPertFunctions.py:31-175,
                                MonotonicityTest.py:51-213]
@@ -210,7 +212,7 @@ def _sha(t):
     return hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
 
 
-def perturb_fixture(name, hw, step, seed, max_bs, patch=None, keep_images=True, blur_k=(11, 5)):
+def perturb_fixture(name, hw, step, seed, max_bs, patch=None, keep_images=True, blur_k=(11, 5), ties=False):
     kern = MAS.gkern(*blur_k)
     blur = lambda t: torch.nn.functional.conv2d(t, kern, padding=blur_k[0] // 2)   # noqa: E731
     # pick the first seed >= `seed` that passes the harness's own usability filter
@@ -227,6 +229,10 @@ def perturb_fixture(name, hw, step, seed, max_bs, patch=None, keep_images=True, 
             break
         seed += 1
     sal = tie_free_map(seed + 2, hw)
+    if ties:
+        # a ReLU'd, coarsely quantised map (what an up-sampled Grad-CAM looks like): most values tie, and the reference's
+        # default np.argsort (unstable, ISA-dependent) decides their order -- recorded below as the order it used HERE
+        sal = (np.maximum(np.round((sal - sal.mean()) / sal.std() * 2.0), 0) / 2.0).astype(np.float32)
     HW = hw * hw
     patch_mask = None
     if patch is not None:
@@ -276,6 +282,9 @@ def perturb_fixture(name, hw, step, seed, max_bs, patch=None, keep_images=True, 
         order = np.flip(np.argsort(sal.reshape(-1, HW), axis=1), axis=-1)
         out["salient_order_desc"] = order.astype(np.int32)
         out["salient_order_asc"] = np.argsort(sal.reshape(-1, HW), axis=1).astype(np.int32)
+        if ties:
+            stable = np.argsort(sal.reshape(HW), kind="stable")
+            out["n_positions_differing_from_the_stable_order"] = np.int64((out["salient_order_asc"][0] != stable).sum())
     out["substrate_blur"] = blur(x).numpy()
     np.savez_compressed(os.path.join(HERE, name), **out)
     print(name, "n_steps+1 =", r[0], "keys:", len(out))
@@ -506,6 +515,7 @@ if __name__ == "__main__":
     perturb_fixture("perturb_small.npz", 32, 32, 300, 10)          # 32 steps, batches 10,10,10,2
     perturb_fixture("perturb_patch.npz", 32, 32, 310, 50, patch=8)  # 16 patches, batch clamps to n_steps
     perturb_fixture("perturb_224.npz", 224, 224, 320, 50, keep_images=False, blur_k=(31, 31))
+    perturb_fixture("perturb_ties.npz", 32, 32, 330, 10, keep_images=False, ties=True)   # tied map: the reference's own (unstable) order recorded
     sweep_fixture()
     vit_fixture()
     cam_fixture()

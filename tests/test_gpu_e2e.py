@@ -208,6 +208,44 @@ def test_single_run_return_tuples(fixture):
         np.testing.assert_array_equal(resp, g["AIC_delflip_ret1"])
 
 
+def test_tied_map_with_the_reference_own_pixel_order():
+    """tests/golden/perturb_ties.npz -- a ReLU'd, quantised map whose pixel order in the reference is whatever its unstable
+    argsort produced (1014 of 1024 positions differ from the stable order).  With that order handed in (keyword-only
+    `salient_order=`), all five metric classes reproduce the reference's return tuples; without it they follow the stable
+    rule, which is a different -- equally valid -- order."""
+    import importlib
+    from oracle import perturb as op
+    g = load_golden("perturb_ties.npz")
+    model = tiny_from(g, DEV)
+    fn = logits_fn_of(model)
+    x, sal = torch.from_numpy(g["x"]), g["saliency"]
+    MAS = importlib.import_module("util.test_methods.MASTestFunctions")
+    kern = MAS.gkern(int(g["blur_klen"]), int(g["blur_sig"]))
+    blur = lambda t: torch.nn.functional.conv2d(t, kern, padding=int(g["blur_klen"]) // 2)      # noqa: E731
+    okern = op.gkern(int(g["blur_klen"]), int(g["blur_sig"]))
+    oblur = lambda im: op.blur_dense(im, okern)                                                   # noqa: E731
+    moved = 0
+    for tag, modname, clsname, mode, uses_blur, ofunc in CASES:
+        descending = (mode != "lerf")
+        order = g["salient_order_desc"][0] if descending else g["salient_order_asc"][0]
+        cls = getattr(importlib.import_module("util.test_methods." + modname), clsname)
+        metric = cls(model, 1024, mode, int(g["step"]), substrate_fn=blur if uses_blur else torch.zeros_like)
+        res = metric.single_run(x.clone(), sal.copy(), DEV, max_batch_size=int(g["max_bs"]), salient_order=order)
+        want = getattr(op, ofunc)(fn, g["x"], sal, mode, int(g["step"]), oblur if uses_blur else np.zeros_like, None, int(g["max_bs"]), order=order)
+        own = metric.single_run(x.clone(), sal.copy(), DEV, max_batch_size=int(g["max_bs"]))
+        for i, (r, w) in enumerate(zip(res, want)):
+            gold = g[f"{tag}_ret{i}"]
+            if np.ndim(w) == 0 and not isinstance(w, float) and ofunc != "mono":
+                assert int(r) == int(w) == int(gold), (tag, i)
+                continue
+            check(f"single_run/perturb_ties.npz/{tag}/ret{i}", r, w, 1e-5, "oracle")
+            check(f"single_run/perturb_ties.npz/{tag}/ret{i}", r, gold, 1e-5)
+            moved += rel_inf(own[i], gold) > 1e-3
+    assert moved >= 5
+    with pytest.raises(ValueError):
+        MAS.MASMetric(model, 1024, "del", 32, torch.zeros_like).single_run(x.clone(), sal, DEV, salient_order=np.zeros(1024, dtype=np.int64))
+
+
 def test_device_blur_substrate_and_mode_asserts():
     from xai_engine.blur import GaussianBlur
     from util.test_methods import MASTestFunctions as MAS
