@@ -24,6 +24,18 @@ def draw_masks(input_size, N, s, p1, rng=np.random):
     return grid, shifts, cell.astype(np.int64)
 
 
+def draw_masks_on_device(input_size, N, s, p1, device, generator=None):
+    """The same draw from the DEVICE generator (torch's Philox): grid (N,s,s) uint8 and shifts (N,2) int32 as device tensors,
+    cell (2,) on the host.  Not the reference's NumPy stream -- statistically equivalent masks, no host RNG loop and no
+    upload ("RISE RNG": bit-parity mode = `draw_masks`, performance mode = this)."""
+    dev = hip_device(device)
+    cell = np.ceil(np.array(input_size) / s).astype(np.int64)
+    grid = (torch.rand((N, s, s), device=dev, generator=generator) < p1).to(torch.uint8)
+    shifts = torch.stack([torch.randint(0, int(cell[0]), (N,), device=dev, generator=generator),
+                          torch.randint(0, int(cell[1]), (N,), device=dev, generator=generator)], dim=1).to(torch.int32)
+    return grid, shifts, cell
+
+
 def generate_masks(input_size, N, s, p1, device=None):
     """(N,1,H,W) masks.  Same RNG stream and values as the reference; returned as float32 on the
     HIP device instead of a float64 host tensor (documented divergence)."""
@@ -49,8 +61,11 @@ def rise(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=N
     grid, shifts, cell = masks if masks is not None else draw_masks((H, W), N, s, p1)
     lo, hi = mask_range if mask_range is not None else (0, N)
     img = image.to(dev, torch.float32).reshape(-1, H, W).contiguous()
-    g_all = torch.from_numpy(np.ascontiguousarray(grid[lo:hi])).to(dev)
-    sh_all = torch.from_numpy(np.ascontiguousarray(shifts[lo:hi])).to(dev)
+    if torch.is_tensor(grid):                                   # a device draw (draw_masks_on_device)
+        g_all, sh_all = grid[lo:hi].to(dev).contiguous(), shifts[lo:hi].to(dev).contiguous()
+    else:
+        g_all = torch.from_numpy(np.ascontiguousarray(grid[lo:hi])).to(dev)
+        sh_all = torch.from_numpy(np.ascontiguousarray(shifts[lo:hi])).to(dev)
     n = hi - lo
     scores = torch.empty(n, dtype=torch.float32, device=dev)
     buf = torch.empty((min(batch_size, max(n, 1)),) + tuple(img.shape), dtype=torch.float32, device=dev)
