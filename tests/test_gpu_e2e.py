@@ -6,7 +6,7 @@ Two comparisons per feature, both through conftest.check, which records the meas
   (a) against the CPU oracle driving the SAME device-resident classifier -> isolates the HIP
       path from MIOpen-vs-oneDNN convolution rounding; bar 1e-5 (BASELINE.json);
   (b) against the golden vectors the reference produced on the CPU (oneDNN classifier) -> bar 1e-5 as well.
-      Measured on an MI355X (profiles/r02_parity.json, 328 comparisons): every (b) comparison is <= 5.3e-6 except
+      Measured on an MI355X (profiles/r02_parity.json, 465 comparisons over the whole suite): every (b) comparison is <= 5.3e-6 except
         * IG on ig_224.npz / ig_tensor_baseline: 2.3e-4 on the 9 pixels under ONE ReLU gate of 20 070 400 whose
           pre-activation is 5.6e-8 (fp64) -- oneDNN rounds it to -3.0e-8, MIOpen to +1.9e-7; everywhere else 4.0e-7,
           and 3.7e-7 everywhere once the host's gates are forced on the device (profiles/r02_gate_flips.json).  So the
