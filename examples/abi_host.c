@@ -23,7 +23,11 @@ static uint32_t lcg_state = 12345u;
 static float rnd(void) { lcg_state = lcg_state * 1664525u + 1013904223u; return (float)((int32_t)(lcg_state >> 8) - (1 << 23)) / (float)(1 << 22); }
 
 int main(void) {
-  if (xai_version() != XAI_ABI_VERSION) { printf("ABI version mismatch\n"); return 1; }
+  /* major must match the header this host was compiled against; the library may be a later minor (entry points only get added) */
+  if (xai_version() != XAI_ABI_VERSION || xai_version_minor() < XAI_ABI_MINOR) {
+    printf("libxai_hip.so has ABI %d.%d, this host was built against %d.%d\n", xai_version(), xai_version_minor(), XAI_ABI_VERSION, XAI_ABI_MINOR);
+    return 1;
+  }
   hipStream_t st;
   CK(hipStreamCreate(&st));
 

@@ -17,6 +17,7 @@ int xai_cu_count() {
 }
 
 XAI_EXPORT int xai_version(void) { return XAI_ABI_VERSION; }
+XAI_EXPORT int xai_version_minor(void) { return XAI_ABI_MINOR; }
 
 XAI_EXPORT const char* xai_strerror(int code) {
   switch (code) {

@@ -8,6 +8,8 @@
 //                      the reference's `mask_clustering[label[i]] += mask[i]` loop, so the sums round identically).
 //   K14 causal_apply   masked = x*m + (noise*scale)*(1-m);  plain = x + (noise*scale)*(1-m)  for N masks, written
 //                      as the [2N][C][HW] stack the classifier consumes.
+//   K16 masked_sums    weighted[p] = (sum_n w_n m_n[p]) / N and plain[p] = (sum_n m_n[p]) / N from ONE read of the mask
+//                      stack (n ascending, fp32, product rounded before the add: bit-identical to two K2 launches).
 // All element-wise, HBM-bound; built with -ffp-contract=off so every a*b+c rounds like the torch expression.
 #include "xai_common.h"
 
@@ -264,7 +266,71 @@ __global__ __launch_bounds__(kBlock) void causal_apply_kernel_v4(const float* __
   }
 }
 
+// K16: lane = W consecutive positions p; walks the N rows in order with 8 independent loads in flight.
+template <int W>
+__global__ __launch_bounds__(kBlock) void masked_sums_kernel(const float* __restrict__ rows, const float* __restrict__ weights, int N,
+                                                             int64_t P, float* __restrict__ out_weighted, float* __restrict__ out_plain) {
+  constexpr int U = 8;
+  const int64_t p = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * W;
+  if (p >= P) return;
+  float aw[W], ap[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) aw[k] = ap[k] = 0.f;
+  const float* r = rows + p;
+  int n = 0;
+  for (; n + U <= N; n += U) {
+    float v[U][W];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (W == 4) {
+        const float4 t = ld4(r + static_cast<int64_t>(n + u) * P);
+        v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+      } else {
+        v[u][0] = r[static_cast<int64_t>(n + u) * P];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float w = weights[n + u];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        aw[k] += v[u][k] * w;
+        ap[k] += v[u][k];
+      }
+    }
+  }
+  for (; n < N; ++n) {
+    const float w = weights[n];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      const float t = r[static_cast<int64_t>(n) * P + k];
+      aw[k] += t * w;
+      ap[k] += t;
+    }
+  }
+  const float denom = static_cast<float>(N);
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    out_weighted[p + k] = aw[k] / denom;
+    out_plain[p + k] = ap[k] / denom;
+  }
+}
+
 }  // namespace
+
+XAI_EXPORT int xai_masked_sums_f32(const float* rows, const float* weights, int N, int64_t P, float* out_weighted, float* out_plain,
+                                   xai_stream_t stream) {
+  XAI_REQUIRE_PTR(rows); XAI_REQUIRE_PTR(weights); XAI_REQUIRE_PTR(out_weighted); XAI_REQUIRE_PTR(out_plain);
+  XAI_REQUIRE(N > 0 && P > 0, XAI_E_SHAPE);
+  if (P % 4 == 0 && xai_aligned16(rows)) {
+    hipLaunchKernelGGL(masked_sums_kernel<4>, dim3(static_cast<unsigned>(xai_ceil_div(P, kBlock * 4))), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), rows, weights, N, P, out_weighted, out_plain);
+  } else {
+    hipLaunchKernelGGL(masked_sums_kernel<1>, dim3(static_cast<unsigned>(xai_ceil_div(P, kBlock))), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), rows, weights, N, P, out_weighted, out_plain);
+  }
+  return xai_launch_status();
+}
 
 XAI_EXPORT int xai_up_rownorm_f32(const float* src, int R, int h, int w, int H, int W, float* out, xai_stream_t stream) {
   XAI_REQUIRE_PTR(src); XAI_REQUIRE_PTR(out);

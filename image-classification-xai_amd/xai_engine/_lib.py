@@ -19,6 +19,7 @@ _d = C.c_double
 # name -> argument types, exactly the prototypes of include/xai_hip.h (return type int unless noted)
 SIGNATURES = {
     "xai_version": [],
+    "xai_version_minor": [],
     "xai_strerror": [_i],
     "xai_ig_interp_f32": [_p, _p, _f, _p, _l, _i, _i, _l, _p, _p],
     "xai_ig_cutoff_f32": [_p, _i, _i, _f, _p, _p],
@@ -46,12 +47,15 @@ SIGNATURES = {
     "xai_rownorm_f32": [_p, _i, _l, _p, _p],
     "xai_cluster_sum_f32": [_p, _p, _p, _i, _l, _p, _p],
     "xai_causal_apply_f32": [_p, _p, _p, _i, _i, _l, _f, _p, _p],
+    "xai_masked_sums_f32": [_p, _p, _i, _l, _p, _p, _p],
     "xai_bn_act_fwd_f32": [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _f, _i, _i, _i, _i, _i, _p, _p],
     "xai_bn_relu_bwd_f32": [_p, _p, _p, _p, _p, _f, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p],
     "xai_maxpool_bwd_f32": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p],
     "xai_bn_relu_maxpool_fwd_f32": [_p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p],
 }
 _RESTYPE = {"xai_strerror": C.c_char_p, "xai_rank_workspace_bytes": C.c_size_t, "xai_gradcam_workspace_bytes": C.c_size_t}
+
+ABI_VERSION, ABI_MINOR = 1, 3       # XAI_ABI_VERSION / XAI_ABI_MINOR of include/xai_hip.h this binding was written against
 
 _lib = None
 
@@ -71,12 +75,20 @@ def load():
             f"{os.path.join(os.path.dirname(_HERE), 'csrc')}` (needs hipcc, targets gfx950). "
             "There is deliberately no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    # version first, by the two symbols every build of the library has had or that say "older" by their absence
+    lib.xai_version.restype = C.c_int
+    major = lib.xai_version()
+    minor = 0
+    if hasattr(lib, "xai_version_minor"):
+        lib.xai_version_minor.restype = C.c_int
+        minor = lib.xai_version_minor()
+    if major != ABI_VERSION or minor < ABI_MINOR:
+        raise XaiHipError(f"{LIB_PATH} has ABI {major}.{minor}, this package needs {ABI_VERSION}.{ABI_MINOR} or a later minor "
+                          f"(include/xai_hip.h); rebuild with `make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}`")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
-    if lib.xai_version() != 1:
-        raise XaiHipError(f"libxai_hip.so ABI version {lib.xai_version()} != 1; rebuild")
     _lib = lib
     return lib
 

@@ -91,17 +91,36 @@ def _path(x, base, alphas, model, batch_size, target_class, want_grads=True):
     return grads, logits
 
 
+def _path_sum(x, base, alphas, model, batch_size, target_class):
+    """Walk the path like `_path`, but keep only the running sum of the step gradients: each pass's autograd gradient
+    (cache-resident, `batch_size` x N) is added straight into a (1,C,H,W) fp32 accumulator by the streaming form of K2.
+    No (steps, N) buffer exists, nothing is filed with a copy and read back.  Per element the sum runs 0 + g_0 + g_1 + ...
+    over ascending steps in fp32 -- the order of the buffered K2 launch, so the two forms are bit-identical
+    (tests/test_gpu_kernels.py::test_ig_streaming_form_equals_buffered, test_IG_streams_when_alpha_star_is_1)."""
+    steps = alphas.shape[0]
+    acc = torch.zeros_like(x)
+    for lo in range(0, steps, batch_size):
+        imgs = K.ig_interp(x, base, alphas[lo:lo + batch_size])[0].requires_grad_(True)
+        g, _ = getGradientsParallel(imgs, model, target_class)
+        K.ig_accum_add(g.reshape(imgs.shape).contiguous(), acc[0])
+    return acc
+
+
 def IG(input, model, steps, batch_size, alpha_star, baseline, device, target_class):
     """IG (alpha_star == 1) / Left-IG of one image (1,C,H,W) -> (C,H,W) on the device
-    (reference saliencyMethods.py:13-72)."""
+    (reference saliencyMethods.py:13-72).
+    alpha_star == 1 needs no per-step state (`gradients.mean(dim=0)`, :53): the step gradients are summed as they are
+    produced (`_path_sum`) and `xai_ig_finish_f32` applies / steps * (x - b).  Left-IG's cutoff depends on all the logits
+    (:48-65), so it keeps the reference's (steps, C,H,W) gradient buffer and reduces its prefix with one K2 launch."""
     if steps % batch_size != 0:
         print("steps must be evenly divisible by batch size: " + str(batch_size) + "!")
         return 0, 0, 0, 0
     dev, x, base = _prep(input, baseline, device)
     alphas = torch.linspace(0, 1, steps).to(dev)          # computed on the host, as the reference does
+    if alpha_star == 1:
+        return K.ig_finish(_path_sum(x, base, alphas, model, batch_size, target_class), steps, x, base)[0]
     grads, logits = _path(x, base, alphas, model, batch_size, target_class)
-    n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)
-    return K.ig_accum(grads, x, base, n_use=n_use)[0]
+    return K.ig_accum(grads, x, base, n_use=K.ig_cutoff(logits, alpha_star))[0]
 
 
 def getSlopes(baseline, baseline_diff, model, steps, batch_size, device, target_class):
@@ -179,12 +198,19 @@ def IDGI(input, model, steps, batch_size, baseline, device, target_class):
 
 
 def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_pass=4, want_abs=False,
-             grads_buffer=None, event_sink=None):
+             grads_buffer=None, event_sink=None, buffered=None):
     """Multi-image IG / Left-IG: x (B,C,H,W) on a HIP device, targets (B,) long.
-    `images_per_pass` images x `steps` interpolants go through the classifier at once; all
-    step gradients land in one [B][steps][C][H][W] buffer that a single accumulation launch
-    reduces (per-image Left-IG cutoffs are computed on the device, no host sync).
+    `images_per_pass` images x `steps` interpolants go through the classifier at once.
     Returns (B,C,H,W) [and the (B,H,W) |sum_c| map the metrics consume].
+    Two data flows, bit-identical per element (fp32 sum over ascending steps, / n, * (x - b)):
+      buffered   all step gradients land in one [B][steps][C][H][W] buffer that a single K2 launch reduces (per-image Left-IG
+                 cutoffs are computed on the device, no host sync).  Needed by Left-IG; it is also the HBM-sized launch
+                 bench.py times for the roofline figure (BASELINE: 32 x 50 x 602 KB = 963 MB).
+      streaming  alpha_star == 1 only: each pass's gradient is added into a (B,C,H,W) accumulator while it is still cache-resident
+                 (xai_ig_accum_add_f32) and xai_ig_finish_f32 scales it -- no buffer, no filing copy, 1/3 of the buffered flow's
+                 HBM traffic.
+    `buffered`: None = buffered exactly when it has to be (alpha_star != 1) or the caller asked for it by passing
+    `grads_buffer` / `event_sink`.
     `event_sink`: optional list that receives (start, end, kernel_start, kernel_stop) torch.cuda.Events of the
     accumulation launch: a pair bracketing it and a pair stamped by the dispatch itself (used by bench.py for the roofline figure)."""
     if not x.is_cuda:
@@ -194,13 +220,20 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
     dev = x.device
     base = baseline.to(dev, torch.float32).contiguous() if torch.is_tensor(baseline) else float(baseline)
     alphas = torch.linspace(0, 1, steps).to(dev)
-    shape = (B, steps) + tuple(x.shape[1:])
-    if grads_buffer is None:
-        grads_buffer = torch.empty(shape, dtype=torch.float32, device=dev)
-    elif tuple(grads_buffer.shape) != shape:
-        raise ValueError(f"grads_buffer must have shape {shape}")
-    logits = torch.empty((B, steps), dtype=torch.float32, device=dev)
+    if buffered is None:
+        buffered = alpha_star != 1 or grads_buffer is not None or event_sink is not None
+    if not buffered and alpha_star != 1:
+        raise ValueError("Left-IG (alpha_star != 1) needs the per-step gradients: buffered=False is for alpha_star == 1 only")
     targets = targets.to(dev).long().reshape(B)
+    shape = (B, steps) + tuple(x.shape[1:])
+    if buffered:
+        if grads_buffer is None:
+            grads_buffer = torch.empty(shape, dtype=torch.float32, device=dev)
+        elif tuple(grads_buffer.shape) != shape:
+            raise ValueError(f"grads_buffer must have shape {shape}")
+        logits = torch.empty((B, steps), dtype=torch.float32, device=dev)
+    else:
+        acc = torch.zeros_like(x)
     for lo in range(0, B, images_per_pass):
         hi = min(lo + images_per_pass, B)
         b = base[lo:hi] if torch.is_tensor(base) else base
@@ -209,8 +242,16 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
         out = _logits_of(model(flat))
         scores = out.gather(1, targets[lo:hi].repeat_interleave(steps).unsqueeze(1)).squeeze(1)
         (g,) = torch.autograd.grad(scores, flat, grad_outputs=torch.ones_like(scores))
-        K.store_grads(g.contiguous(), grads_buffer[lo:hi])
-        logits[lo:hi] = scores.detach().view(hi - lo, steps)
+        g = g.contiguous()
+        if buffered:
+            K.store_grads(g, grads_buffer[lo:hi])
+            logits[lo:hi] = scores.detach().view(hi - lo, steps)
+        else:
+            g = g.view((hi - lo, steps) + tuple(x.shape[1:]))
+            for j in range(hi - lo):
+                K.ig_accum_add(g[j], acc[lo + j])
+    if not buffered:
+        return K.ig_finish(acc, steps, x, base, want_abs=want_abs)
     n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)
     if event_sink is None:
         return K.ig_accum(grads_buffer, x, base, n_use=n_use, want_abs=want_abs)

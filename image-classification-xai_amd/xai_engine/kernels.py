@@ -350,6 +350,18 @@ def cluster_sum(rows, members, offs):
     return out
 
 
+def masked_sums(rows, weights):
+    """rows (N,P), weights (N,) -> (sum_n w_n rows_n / N, sum_n rows_n / N), each (P,): one read of the stack."""
+    _need(rows, F32, "rows"); _need(weights, F32, "weights")
+    N, P = rows.shape
+    if weights.numel() != N:
+        raise ValueError("one weight per row")
+    weighted = torch.empty(P, dtype=F32, device=rows.device)
+    plain = torch.empty(P, dtype=F32, device=rows.device)
+    _call("xai_masked_sums_f32", rows.device, _ptr(rows), _ptr(weights), N, P, _ptr(weighted), _ptr(plain))
+    return weighted, plain
+
+
 def causal_apply(x, masks, noise, noise_scale=0.1):
     """x (C,H,W); masks (N,H*W); noise (N,C,H,W) standard normal -> (2N,C,H,W): masked+noise rows then image+noise rows."""
     _need(x, F32, "x"); _need(masks, F32, "masks"); _need(noise, F32, "noise")

@@ -32,13 +32,20 @@ extern "C" {
 
 typedef void* xai_stream_t; /* hipStream_t */
 
+/* xai_version() = XAI_ABI_VERSION: bumped when an existing prototype or its documented meaning changes.
+ * xai_version_minor() = XAI_ABI_MINOR: bumped whenever entry points are added or an accepted argument range grows, so a
+ * host can tell an older libxai_hip.so from this one without probing symbols:
+ *   1 = the round-1 set;  2 = + xai_ig_accum_timed_f32, xai_maxpool_bwd_f32 accepts more than 65 535 planes;
+ *   3 = + xai_version_minor, xai_masked_sums_f32 */
 #define XAI_ABI_VERSION 1
+#define XAI_ABI_MINOR 3
 #define XAI_OK 0
 #define XAI_E_NULL (-1)        /* required pointer is NULL                      */
 #define XAI_E_SHAPE (-2)       /* non-positive / inconsistent extent, or misaligned */
 #define XAI_E_UNSUPPORTED (-3) /* extent beyond what the kernel was built for   */
 
 int xai_version(void);
+int xai_version_minor(void);
 /* static string for a code returned by any entry point (never NULL) */
 const char* xai_strerror(int code);
 
@@ -217,6 +224,14 @@ int xai_cluster_sum_f32(const float* rows, const int32_t* members, const int32_t
  *   x : [C][HW];  masks : [N][HW];  noise : [N][C][HW] standard normal draws;  stack : [2N][C][HW] */
 int xai_causal_apply_f32(const float* x, const float* masks, const float* noise, int N, int C,
                          int64_t HW, float noise_scale, float* stack, xai_stream_t stream);
+
+/* K16 out_weighted[p] = (sum_n weights[n] * rows[n][p]) / N;  out_plain[p] = (sum_n rows[n][p]) / N   -- ONE read of the
+ *     stored mask stack (n ascending, fp32, each product rounded before it is added)
+ * replaces  (scores * masks).sum / masks.sum of TIS.generate_saliency, util/attribution_methods/TIS.py:331-366, and the
+ *           matmul(p_final, masks / masks.sum(0)) of ViT_CX/causal_score.py:54-61 restricted to the one class row consumed
+ *   rows : [N][P];  weights : [N];  out_weighted, out_plain : [P] */
+int xai_masked_sums_f32(const float* rows, const float* weights, int N, int64_t P, float* out_weighted,
+                        float* out_plain, xai_stream_t stream);
 
 /* ---- opt-in classifier-side fusion (xai_engine/prepare.py: fuse_bn_relu) --------------- */
 

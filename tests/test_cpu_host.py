@@ -48,7 +48,9 @@ def test_ctypes_table_matches_header_and_library_loads():
     from xai_engine import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.xai_version() == 1
+    hdr = open(HEADER).read()
+    assert lib.xai_version() == _lib.ABI_VERSION == int(re.search(r"#define XAI_ABI_VERSION (\d+)", hdr).group(1))
+    assert lib.xai_version_minor() == _lib.ABI_MINOR == int(re.search(r"#define XAI_ABI_MINOR (\d+)", hdr).group(1))
     assert b"NULL" in lib.xai_strerror(-1) and lib.xai_strerror(0) == b"success"
     assert lib.xai_rank_workspace_bytes(2, 50176) == 2 * (4 * 50176 + 5 * 256 * 49 + 8) * 4      # keys+idx ping-pong, 4 hists + offs, flags
     # argument validation happens before any HIP call, so it is checkable without a GPU
@@ -59,7 +61,7 @@ def test_ctypes_table_matches_header_and_library_loads():
 def test_every_header_entry_cites_the_reference_line_it_replaces():
     src = open(HEADER).read()
     for name in _declared():
-        if name in ("xai_version", "xai_strerror", "xai_rank_workspace_bytes", "xai_gradcam_workspace_bytes", "xai_flip_steps_i32", "xai_ig_finish_f32",
+        if name in ("xai_version", "xai_version_minor", "xai_strerror", "xai_rank_workspace_bytes", "xai_gradcam_workspace_bytes", "xai_flip_steps_i32", "xai_ig_finish_f32",
                     "xai_idgi_accum_f32"):
             continue
         at = src.index(name + "(")
@@ -370,7 +372,7 @@ def test_the_header_is_plain_c_and_a_c_host_links_against_the_library(tmp_path):
     exe = _build_abi_host(tmp_path / "abi_host")
     out = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
     used = sorted({l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("xai_")})
-    assert used == ["xai_flip_steps_i32", "xai_ig_accum_f32", "xai_perturb_batch_f32", "xai_rank_f32", "xai_rank_workspace_bytes", "xai_strerror", "xai_version"]
+    assert used == ["xai_flip_steps_i32", "xai_ig_accum_f32", "xai_perturb_batch_f32", "xai_rank_f32", "xai_rank_workspace_bytes", "xai_strerror", "xai_version", "xai_version_minor"]
 
 
 def test_class_quota_replays_the_reference_loop_order():

@@ -87,6 +87,51 @@ def test_ig_batch_equals_per_image(attr):
             assert rel_inf(out_abs[i].cpu().numpy(), np.abs(one.cpu().numpy().sum(0))) <= 2e-6
 
 
+def test_IG_streams_when_alpha_star_is_1_and_equals_the_buffered_flow_bit_for_bit(attr, monkeypatch):
+    """alpha_star == 1: IG() and ig_batch() sum each pass's gradient straight into a (C,H,W) accumulator -- no (steps, N) buffer, no
+    filing copy -- and the result is bit-identical to the buffered K2 launch Left-IG and bench.py keep."""
+    from xai_engine import kernels as K
+    from xai_engine.ig import ig_batch
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    x = torch.from_numpy(g["x"])
+    t = torch.tensor(int(g["target"]))
+    calls = {"store": 0, "accum": 0, "add": 0}
+    real_store, real_accum, real_add = K.store_grads, K.ig_accum, K.ig_accum_add
+    monkeypatch.setattr(K, "store_grads", lambda *a, **k: (calls.__setitem__("store", calls["store"] + 1), real_store(*a, **k))[1])
+    monkeypatch.setattr(K, "ig_accum", lambda *a, **k: (calls.__setitem__("accum", calls["accum"] + 1), real_accum(*a, **k))[1])
+    monkeypatch.setattr(K, "ig_accum_add", lambda *a, **k: (calls.__setitem__("add", calls["add"] + 1), real_add(*a, **k))[1])
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    before = torch.cuda.memory_allocated()
+    streamed = attr.IG(x.clone(), model, 50, 25, 1, 0.25, DEV, t)
+    peak = torch.cuda.max_memory_allocated() - before
+    assert calls == {"store": 0, "accum": 0, "add": 2}
+    n_bytes = x.numel() * 4
+    assert peak < 50 * n_bytes, (peak, 50 * n_bytes)                 # the 50-step gradient buffer alone would be 50 x N x 4 bytes
+    xs = x.to(DEV)
+    buffered = ig_batch(xs, model, t.reshape(1), steps=50, alpha_star=1, baseline=0.25, images_per_pass=1, buffered=True)
+    assert calls["store"] == 1 and calls["accum"] == 1
+    np.testing.assert_array_equal(streamed.cpu().numpy(), buffered[0].cpu().numpy())
+    # the batched engine: default = streaming for alpha_star == 1, buffered for Left-IG; both flows agree bit for bit
+    xs5 = torch.randn(5, 3, 32, 32, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        ts = model(xs5).argmax(1)
+    base = torch.randn(5, 3, 32, 32, generator=torch.Generator().manual_seed(6)).to(DEV)
+    for b in (0, base):
+        calls.update(store=0, accum=0, add=0)
+        s_out, s_abs = ig_batch(xs5, model, ts, steps=50, baseline=b, images_per_pass=2, want_abs=True)
+        assert calls == {"store": 0, "accum": 0, "add": 5}
+        b_out, b_abs = ig_batch(xs5, model, ts, steps=50, baseline=b, images_per_pass=2, want_abs=True, buffered=True)
+        np.testing.assert_array_equal(s_out.cpu().numpy(), b_out.cpu().numpy())
+        np.testing.assert_array_equal(s_abs.cpu().numpy(), b_abs.cpu().numpy())
+    calls.update(store=0, accum=0, add=0)
+    ig_batch(xs5, model, ts, steps=50, alpha_star=.9, images_per_pass=2)
+    assert calls["accum"] == 1 and calls["add"] == 0
+    with pytest.raises(ValueError):
+        ig_batch(xs5, model, ts, steps=50, alpha_star=.9, buffered=False)
+
+
 def test_IDG_IDGI_and_helpers(attr):
     from oracle import ig as oig
     g = load_golden("ig_small.npz")

@@ -442,6 +442,26 @@ def test_tis_and_vitcx_accumulators(K):
     assert rel_inf(got, want) <= 5e-6
 
 
+@pytest.mark.parametrize("N,P", [(1024, 196), (130, 224 * 224), (7, 30 * 45 + 1), (1, 4), (19, 3)])
+def test_masked_sums_one_pass_equals_two_K2_launches_bit_for_bit(K, N, P):
+    """K16 reads the mask stack once; the weighted and the plain mean it returns are bit-identical to the two K2 launches
+    (weighted form / plain form) that served TIS and ViT-CX before, and to fp32 sequential sums."""
+    rng = np.random.default_rng(N * 7 + P)
+    rows = rng.random((N, P)).astype(np.float32)
+    w = rng.standard_normal(N).astype(np.float32)
+    weighted, plain = K.masked_sums(dev(rows), dev(w))
+    g = dev(rows).view(1, N, 1, P)
+    ones = torch.ones((1, 1, P), device=DEV)
+    np.testing.assert_array_equal(weighted.cpu().numpy(), K.ig_accum(g, ones, 0.0, w1=dev(w).reshape(1, N))[0, 0].cpu().numpy())
+    np.testing.assert_array_equal(plain.cpu().numpy(), K.ig_accum(g, ones, 0.0)[0, 0].cpu().numpy())
+    aw, ap = np.zeros(P, np.float32), np.zeros(P, np.float32)
+    for n in range(N):
+        aw += rows[n] * w[n]
+        ap += rows[n]
+    np.testing.assert_array_equal(weighted.cpu().numpy(), aw / np.float32(N))
+    np.testing.assert_array_equal(plain.cpu().numpy(), ap / np.float32(N))
+
+
 # ------------------------------------------------------------------------------ K11-K14 feature-map maskers (ViT-CX)
 @pytest.mark.parametrize("shape", [(12, 4, 4, 32, 32), (768, 14, 14, 224, 224), (5, 3, 7, 30, 45)])
 def test_up_rownorm_vs_oracle(K, shape):
