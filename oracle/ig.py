@@ -104,6 +104,38 @@ def ig(x, model, steps, batch_size, alpha_star, baseline, target, return_path=Fa
     return (out, grads, logits, n_use) if return_path else out
 
 
+def grads_and_logits_rows(model, batch, targets):
+    """`grads_and_logits` with one target class per row: row r is scored by logit[targets[r]].  Rows are independent in
+    the classifier (eval mode), so this is getGradientsParallel [saliencyMethods.py:209-215] applied to several images'
+    interpolants stacked into one classifier batch."""
+    x = torch.from_numpy(np.ascontiguousarray(batch)).to(_device_of(model)).requires_grad_(True)
+    out = model(x)
+    out = out if isinstance(out, torch.Tensor) else out.logits
+    idx = torch.as_tensor(np.asarray(targets, dtype=np.int64)).to(out.device)
+    score = out.gather(1, idx.unsqueeze(1)).squeeze(1)
+    (g,) = torch.autograd.grad(score, x, grad_outputs=torch.ones_like(score))
+    return g.detach().cpu().numpy(), score.detach().cpu().numpy()
+
+
+def ig_stacked(xs, model, steps, images_per_pass, baseline, targets):
+    """The reference's IG (alpha_star == 1) [saliencyMethods.py:13-72] for several images whose interpolants share classifier
+    passes: `images_per_pass` images x `steps` interpolants ([image][step] order) form one batch -- a batch the reference's
+    one-image signature cannot form (:14-16) but bench.py's headline configuration runs.  Everything outside the classifier
+    call is the one-image oracle (`interpolate`, `accumulate`).  xs: (B,C,H,W) -> (B,C,H,W)."""
+    xs = np.asarray(xs, dtype=F32)
+    al = linspace01(steps)
+    out = np.zeros_like(xs)
+    for lo in range(0, xs.shape[0], images_per_pass):
+        part = xs[lo:lo + images_per_pass]
+        bases = [as_baseline(x, baseline) for x in part]
+        batch = np.concatenate([interpolate(x, b, al) for x, b in zip(part, bases)])
+        rows = np.repeat(np.asarray(targets[lo:lo + images_per_pass], dtype=np.int64), steps)
+        grads, _ = grads_and_logits_rows(model, batch, rows)
+        for j, (x, b) in enumerate(zip(part, bases)):
+            out[lo + j] = accumulate(grads[j * steps:(j + 1) * steps], steps, x, b)
+    return out
+
+
 def slopes(x, base, model, steps, batch_size, target):
     """Finite-difference logit slopes on the uniform path [saliencyMethods.py:226-261]."""
     al = linspace01(steps)

@@ -78,16 +78,30 @@ def test_config2_ig_resnet50(resnet):
     for i in range(2):
         check(f"config2/ig_batch_resnet50/{i}", out[i].cpu().numpy(), want[i], 1e-5, "oracle")
         check(f"config2/ig_batch_abs_resnet50/{i}", out_abs[i].cpu().numpy(), np.abs(want[i].sum(0)), 1e-5, "oracle")
-    # bench.py runs 2 images (100 interpolants) per pass.  MIOpen then runs other (deterministic) solvers, the logits move by
-    # ~1e-6, and a 50-layer ReLU network turns that into flipped gates: single pixels of the 50-step mean move by up to 6.6e-4
-    # of the map's maximum (measured, profiles/r02_parity.json) -- the classifier's own batch-size dependence (it is there
-    # between model(x[:50]) and model(x[:100])[:50] in plain PyTorch too), not the attribution kernels': those are held to
-    # the bar above with the batches equal (measured: bit-identical); in the l2 sense the two maps differ by 2.2e-4.  Both bounds = 2 x measured.
-    out2, _ = ig_batch(xs.to(DEV), resnet, ts, steps=50, images_per_pass=2, want_abs=True)
-    for i in range(2):
-        check(f"config2/ig_batch_2_images_per_pass_vs_1/{i}", out2[i].cpu().numpy(), out[i].cpu().numpy(), 1.3e-3, "1 image per pass")
-        a, b = out2[i].double().cpu().numpy(), out[i].double().cpu().numpy()
-        check(f"config2/ig_batch_2_images_per_pass_vs_1_l2/{i}", np.linalg.norm(a - b) / np.linalg.norm(b), 0.0, 4.4e-4, "1 image per pass", absolute=True)
+
+
+def test_config2_benched_composition_two_images_per_pass(resnet):
+    """bench.py's headline step runs 2 images = 100 interpolants per classifier pass, a batch the reference's one-image API cannot
+    form.  Held here against the ORACLE driven with the very same batches (oracle.ig.ig_stacked: two images' interpolants
+    concatenated, same device model, deterministic solvers): both sides then see bit-identical classifier outputs and the
+    comparison isolates K1 / the gradient filing / K2 -- measured 0.0 (bit-identical), asserted at the 1e-5 bar.  (What the
+    two-image batch changes is the classifier: MIOpen picks other solvers for batch 100 than for batch 50, ReLU gates of single
+    pixels flip, and model(x[:50]) differs from model(x[:100])[:50] by ~1e-6 in plain PyTorch too.  That is why the 1e-5 claim
+    against the REFERENCE is made on `parity_mode` -- one image per pass -- and this test pins the headline's own kernels.)"""
+    from xai_engine.ig import ig_batch
+    from oracle import ig as oig
+    xs = torch.cat([_image(2), _image(12), _image(22)])          # three images: a full pass of two and a ragged last pass of one
+    with torch.no_grad():
+        ts = resnet(xs.to(DEV)).argmax(1)
+    want = oig.ig_stacked(xs.numpy(), resnet, 50, 2, 0, ts.cpu().numpy())
+    grads = torch.empty((3, 50, 3, 224, 224), device=DEV)
+    out, out_abs = ig_batch(xs.to(DEV), resnet, ts, steps=50, images_per_pass=2, want_abs=True, grads_buffer=grads)     # bench.py's call
+    streamed = ig_batch(xs.to(DEV), resnet, ts, steps=50, images_per_pass=2)
+    for i in range(3):
+        check(f"config2/benched_2_images_per_pass/{i}", out[i].cpu().numpy(), want[i], 1e-5, "oracle on the same 100-interpolant batches")
+        check(f"config2/benched_2_images_per_pass_abs/{i}", out_abs[i].cpu().numpy(), np.abs(want[i].sum(0)), 1e-5,
+              "oracle on the same 100-interpolant batches")
+        np.testing.assert_array_equal(streamed[i].cpu().numpy(), out[i].cpu().numpy())
 
 
 def test_config3_rise_resnet50_200_masks(resnet):
