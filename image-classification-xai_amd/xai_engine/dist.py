@@ -49,14 +49,28 @@ def mask_range(n_masks, rank, world):
 def broadcast_masks(masks, device, src=0):
     """Make every rank use rank `src`'s RNG draw (grid uint8 (N,s,s), shifts int32 (N,2), cell (2,)): ONE broadcast of
     the three arrays packed into a byte buffer (N = 8000, s = 8: 576 016 B).  Every rank passes a draw of the same
-    (N, s) -- its own is simply overwritten -- so the packed size is known everywhere without a size exchange."""
+    (N, s) -- its own is simply overwritten -- so the packed size is known everywhere without a size exchange.
+    A NumPy draw (`rise.draw_masks`, the reference's RNG stream) comes back as NumPy arrays; a device draw
+    (`rise.draw_masks_on_device`: torch tensors) is packed, broadcast and unpacked on the device and comes back as tensors
+    there -- no host round trip under RCCL (gloo stages through the host by itself)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return masks
     on = device if dist.get_backend() == "nccl" else torch.device("cpu")
     grid, shifts, cell = masks
+    cell = np.asarray(cell, dtype=np.int64).reshape(2)
+    if torch.is_tensor(grid) or torch.is_tensor(shifts):
+        home = grid.device if torch.is_tensor(grid) else shifts.device
+        g = torch.as_tensor(grid).to(home, torch.uint8).contiguous()
+        sh = torch.as_tensor(shifts).to(home, torch.int32).contiguous()
+        c = torch.from_numpy(cell.copy()).to(home)
+        packed = torch.cat([g.reshape(-1), sh.reshape(-1).view(torch.uint8), c.view(torch.uint8)]).to(on)
+        dist.broadcast(packed, src=src)
+        got = packed.to(home)
+        ng, ns = g.numel(), sh.numel() * 4
+        return (got[:ng].reshape(g.shape).clone(), got[ng:ng + ns].clone().view(torch.int32).reshape(sh.shape),
+                got[ng + ns:].clone().view(torch.int64).cpu().numpy())
     grid = np.ascontiguousarray(grid, dtype=np.uint8)
     shifts = np.ascontiguousarray(shifts, dtype=np.int32)
-    cell = np.asarray(cell, dtype=np.int64).reshape(2)
     packed = np.concatenate([grid.reshape(-1), shifts.reshape(-1).view(np.uint8), cell.view(np.uint8)])
     t = torch.from_numpy(packed).to(on)
     dist.broadcast(t, src=src)
@@ -78,7 +92,7 @@ def all_reduce_sum(t):
     return t
 
 
-def rise_sharded(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=None, batch_size=50, masks=None):
+def rise_sharded(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=None, batch_size=50, masks=None, streams=1):
     """RISE with the N masks split over the ranks: every rank scores its contiguous range and
     accumulates an fp64 partial; one all-reduce merges them.  Returns the (H,W) fp32 map on
     every rank.  All ranks use rank 0's mask draw."""
@@ -90,7 +104,7 @@ def rise_sharded(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, sc
         masks = draw_masks((H, W), N, s, p1)
     masks = broadcast_masks(masks, torch.device(device))
     part = rise(model, image, txt_embedding, device, N=N, s=s, p1=p1, score_fn=score_fn, batch_size=batch_size, masks=masks,
-                mask_range=mask_range(N, rank, world), return_partial=True)
+                mask_range=mask_range(N, rank, world), return_partial=True, streams=streams)
     return all_reduce_sum(part).float()
 
 

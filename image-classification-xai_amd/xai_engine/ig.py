@@ -197,8 +197,19 @@ def IDGI(input, model, steps, batch_size, baseline, device, target_class):
     return K.idgi_accum(g, logits[0].contiguous(), K.sumsq(g))
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev, n):
+    """n HIP streams per device, created once (stream creation is not free and hipGraph-unfriendly)."""
+    have = _SIDE_STREAMS.setdefault(str(dev), [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(dev))
+    return have[:n]
+
+
 def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_pass=4, want_abs=False,
-             grads_buffer=None, event_sink=None, buffered=None):
+             grads_buffer=None, event_sink=None, buffered=None, streams=1):
     """Multi-image IG / Left-IG: x (B,C,H,W) on a HIP device, targets (B,) long.
     `images_per_pass` images x `steps` interpolants go through the classifier at once.
     Returns (B,C,H,W) [and the (B,H,W) |sum_c| map the metrics consume].
@@ -211,6 +222,10 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
                  HBM traffic.
     `buffered`: None = buffered exactly when it has to be (alpha_star != 1) or the caller asked for it by passing
     `grads_buffer` / `event_sink`.
+    `streams` > 1: consecutive classifier passes are queued round-robin on that many HIP streams, so the low-occupancy layers
+    of one pass (7x7 feature maps, the stem's backward) overlap another pass's work.  Every pass still launches the same kernels
+    on the same shapes and writes disjoint rows, so the result is bit-identical to `streams=1`
+    (tests/test_gpu_e2e.py::test_ig_batch_passes_on_several_streams).
     `event_sink`: optional list that receives (start, end, kernel_start, kernel_stop) torch.cuda.Events of the
     accumulation launch: a pair bracketing it and a pair stamped by the dispatch itself (used by bench.py for the roofline figure)."""
     if not x.is_cuda:
@@ -234,8 +249,7 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
         logits = torch.empty((B, steps), dtype=torch.float32, device=dev)
     else:
         acc = torch.zeros_like(x)
-    for lo in range(0, B, images_per_pass):
-        hi = min(lo + images_per_pass, B)
+    def one_pass(lo, hi):
         b = base[lo:hi] if torch.is_tensor(base) else base
         imgs = K.ig_interp(x[lo:hi], b, alphas)                                  # (k, steps, C,H,W)
         flat = imgs.view((-1,) + tuple(x.shape[1:])).requires_grad_(True)
@@ -250,6 +264,24 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
             g = g.view((hi - lo, steps) + tuple(x.shape[1:]))
             for j in range(hi - lo):
                 K.ig_accum_add(g[j], acc[lo + j])
+
+    spans = [(lo, min(lo + images_per_pass, B)) for lo in range(0, B, images_per_pass)]
+    n_streams = max(1, min(int(streams), len(spans)))
+    if n_streams == 1:
+        for lo, hi in spans:
+            one_pass(lo, hi)
+    else:
+        main = torch.cuda.current_stream(dev)
+        side = _side_streams(dev, n_streams)
+        ready = torch.cuda.Event()
+        ready.record(main)                                   # x, alphas, targets, the zeroed accumulator
+        for st in side:
+            st.wait_event(ready)
+        for i, (lo, hi) in enumerate(spans):
+            with torch.cuda.stream(side[i % n_streams]):
+                one_pass(lo, hi)
+        for st in side:
+            main.wait_stream(st)
     if not buffered:
         return K.ig_finish(acc, steps, x, base, want_abs=want_abs)
     n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)

@@ -48,13 +48,15 @@ def generate_masks(input_size, N, s, p1, device=None):
 
 
 def rise(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=None, batch_size=50,
-         masks=None, mask_range=None, return_partial=False):
+         masks=None, mask_range=None, return_partial=False, streams=1):
     """Saliency (H,W) float32 on the device = sum_i score_i * mask_i / N / p1.
 
     Reference call shape: rise(model, image, txt_embedding, device, N, s, p1) with the CLIP cosine
     score.  Extensions (keyword-only): `score_fn(batch) -> (B,)` for a plain classifier,
     `masks=(grid, shifts, cell)` to reuse a draw, `mask_range=(lo, hi)` to process a shard of the
-    masks (multi-GPU), `return_partial` to get the un-rounded fp64 partial sum for an all-reduce.
+    masks (multi-GPU), `return_partial` to get the un-rounded fp64 partial sum for an all-reduce,
+    `streams` > 1 to queue consecutive mask batches round-robin on that many HIP streams (each with its own batch buffer; the
+    batches write disjoint score slices, so the map is bit-identical to `streams=1`).
     """
     dev = hip_device(device)
     H, W = int(image.shape[-2]), int(image.shape[-1])
@@ -68,16 +70,33 @@ def rise(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=N
         sh_all = torch.from_numpy(np.ascontiguousarray(shifts[lo:hi])).to(dev)
     n = hi - lo
     scores = torch.empty(n, dtype=torch.float32, device=dev)
-    buf = torch.empty((min(batch_size, max(n, 1)),) + tuple(img.shape), dtype=torch.float32, device=dev)
+    spans = [(i, min(i + batch_size, n)) for i in range(0, n, batch_size)]
+    n_streams = max(1, min(int(streams), len(spans)))
+    bufs = [torch.empty((min(batch_size, max(n, 1)),) + tuple(img.shape), dtype=torch.float32, device=dev) for _ in range(n_streams)]
+
+    def one_batch(i, j, buf):
+        masked = K.rise_apply(g_all[i:j], sh_all[i:j], cell, img, out=buf[:j - i])
+        if score_fn is not None:
+            scores[i:j] = score_fn(masked).reshape(-1).float()
+        else:
+            feats = F.normalize(model.encode_image(masked), dim=-1)
+            scores[i:j] = (feats @ txt_embedding.T).reshape(-1).float()
+
     with torch.no_grad():
-        for i in range(0, n, batch_size):
-            j = min(i + batch_size, n)
-            masked = K.rise_apply(g_all[i:j], sh_all[i:j], cell, img, out=buf[:j - i])
-            if score_fn is not None:
-                scores[i:j] = score_fn(masked).reshape(-1).float()
-            else:
-                feats = F.normalize(model.encode_image(masked), dim=-1)
-                scores[i:j] = (feats @ txt_embedding.T).reshape(-1).float()
+        if n_streams == 1:
+            for i, j in spans:
+                one_batch(i, j, bufs[0])
+        else:
+            from .ig import _side_streams
+            main = torch.cuda.current_stream(dev)
+            side = _side_streams(dev, n_streams)
+            for st in side:
+                st.wait_stream(main)                            # image, grid, shifts, the buffers
+            for k, (i, j) in enumerate(spans):
+                with torch.cuda.stream(side[k % n_streams]):
+                    one_batch(i, j, bufs[k % n_streams])
+            for st in side:
+                main.wait_stream(st)
     acc = torch.zeros((H, W), dtype=torch.float64, device=dev)
     if n > 0:
         K.rise_accum(g_all, sh_all, scores, cell, H, W, 1.0 / N / p1, acc=acc)

@@ -9,6 +9,8 @@ eight runs contain (insert-blur-descending, delete-zero-descending, delete-zero-
 compare MASTestFunctions.py:137-185, AICTestFunctions.py:94-123, PosNegPertFunctions.py:73-119,
 MonotonicityTest.py:93-120): 3 + 3*n_steps classifier passes instead of ~8*(n_steps+3).
 """
+import collections
+import contextlib
 import csv
 import os
 import time
@@ -64,7 +66,8 @@ def get_CNN_attr(input_tensor, trans_img, target_class, testing_dict):
         # launch-bound one-image pass is one hipGraph replay (captured once per model and input shape)
         x = input_tensor.to(dev)
         if testing_dict.get("capture_gradcam"):
-            key = (id(model), tuple(x.shape), str(dev))
+            # one graph per stream: a replay reads and writes the graph's static buffers, so two streams must not share one
+            key = (id(model), tuple(x.shape), str(dev), torch.cuda.current_stream(dev).cuda_stream)
             cache = testing_dict.setdefault("_captured_gradcam", {})
             if key not in cache:
                 cache[key] = CapturedGradCam(model, model.layer4, x, (img_hw, img_hw))
@@ -332,7 +335,7 @@ class SweepState:
 
 
 def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fused=True, rank=0, world=1, testing_dict=None,
-                 checkpoint=None, checkpoint_every=25, identity=None):
+                 checkpoint=None, checkpoint_every=25, identity=None, streams=1):
     """Attribution + ten perturbation numbers for every image this rank owns; returns the
     globally reduced (Counter of sums, images used, seconds in attribution).
     images: sequence of (1,C,H,W) CPU/device tensors (already selected -- the order-dependent
@@ -342,7 +345,14 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     interrupted sweep with the same split and the same `identity` resumes after the last saved image; a checkpoint
     of another split or identity raises CheckpointMismatch.  `identity`: string from `sweep_identity(...)` naming
     what the caller's attr_fn / image list are (the harness passes attr_func, model name, file-name hash, ...); the
-    flow (fused / eight runs), geometry and a fingerprint of the classifier's weights are always added here."""
+    flow (fused / eight runs), geometry and a fingerprint of the classifier's weights are always added here.
+    `streams` > 1 (fused flow): consecutive images are queued round-robin on that many HIP streams -- attribution, ranking and the
+    three step sequences of one image form a serial chain of mostly small or low-occupancy launches, so the chains of `streams`
+    images overlap on the chip.  Every image still runs the same kernels on the same shapes and the per-image Counters are folded
+    in image order, so the sums are bit-identical to `streams=1` (tests/test_gpu_e2e.py::test_sweep_images_on_several_streams).
+    The third return value, seconds in attribution, is measured with HIP events on the image's stream when the map stays on the
+    device (the reference times a finished attribution, evaluatePerturbation.py:581-590; the host clock around an asynchronous
+    launch would only see the enqueue)."""
     dev = hip_device(device)
     sweep = PerturbationSweep(model, img_hw, dev, batch_size=batch_size) if fused else None
     td = testing_dict or {"models": [model], "img_hw": img_hw, "batch_size": batch_size, "device": str(dev)}
@@ -361,40 +371,65 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
         if checkpoint and (st.next_pos % checkpoint_every == 0 or st.next_pos == len(mine)):
             st.save(checkpoint)
 
-    pending = None                                       # (handle, pos) of the image whose device work is in flight
+    n_streams = max(1, int(streams)) if fused else 1
+    side = None
+    main_stream = torch.cuda.current_stream(dev)
+    if n_streams > 1:
+        from .ig import _side_streams
+        side = _side_streams(dev, n_streams)
+        for s_ in side:                                  # weights, blur taps: whatever the caller's stream has queued so far
+            s_.wait_stream(torch.cuda.current_stream(dev))
+    pending = collections.deque()                        # (handle, pos, attribution timer) of the images whose device work is in flight
     failed = None
+
+    def finish_oldest():
+        handle, pos, timer = pending.popleft()
+        c = sweep.finish(handle)
+        if timer is not None:                            # the events lie before `done` on the same stream: complete by now
+            st.attr_time += timer[0].elapsed_time(timer[1]) * 1e-3
+        fold(c, pos)
+
     try:
         for pos in range(st.next_pos, len(mine)):
             x = images[mine[pos]]
-            if fused and not x.is_cuda:
-                # one upload through pinned memory, queued behind the previous image's work: a pageable .to(dev) blocks the
-                # host until the stream has drained, which would undo the one-image-deep pipelining
-                x = x.to(torch.float32).contiguous().pin_memory().to(dev, non_blocking=True)
-            with torch.no_grad():
-                target = _logits_of(model(x.to(dev))).argmax(1)[0]
-            t0 = time.time()
-            sal = attr_fn(x, target)
-            st.attr_time += time.time() - t0
-            if fused:
-                # one image deep: queue this image's device work, then do the previous image's host arithmetic while it runs
-                handle = sweep.launch(x, sal)
-                if pending is not None:
-                    done, pending = pending, None
-                    fold(sweep.finish(done[0]), done[1])
-                pending = (handle, pos)
-            else:
-                fold(run_perturbation(x.cpu(), sal, td, blur=blur), pos)
+            with (torch.cuda.stream(side[pos % n_streams]) if side else contextlib.nullcontext()):
+                if side and x.is_cuda:                   # a device image the caller produced on ITS stream a moment ago
+                    torch.cuda.current_stream(dev).wait_stream(main_stream)
+                if fused and not x.is_cuda:
+                    # one upload through pinned memory, queued behind the previous image's work: a pageable .to(dev) blocks the
+                    # host until the stream has drained, which would undo the pipelining
+                    x = x.to(torch.float32).contiguous().pin_memory().to(dev, non_blocking=True)
+                with torch.no_grad():
+                    target = _logits_of(model(x.to(dev))).argmax(1)[0]
+                timer = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                t0 = time.time()
+                timer[0].record(torch.cuda.current_stream(dev))
+                sal = attr_fn(x, target)
+                timer[1].record(torch.cuda.current_stream(dev))
+                if not (torch.is_tensor(sal) and sal.is_cuda):
+                    st.attr_time += time.time() - t0     # a host map: attr_fn has waited for the device itself
+                    timer = None
+                if fused:
+                    # `n_streams` images deep: queue this image's device work, then do the oldest image's host arithmetic
+                    pending.append((sweep.launch(x, sal), pos, timer))
+                    while len(pending) > n_streams:
+                        finish_oldest()
+                else:
+                    if timer is not None:
+                        timer[1].synchronize()
+                        st.attr_time += timer[0].elapsed_time(timer[1]) * 1e-3
+                    fold(run_perturbation(x.cpu(), sal, td, blur=blur), pos)
     except BaseException as e:
         failed = e
         raise
     finally:
-        if pending is not None:                          # also on an exception: the queued image is complete work, keep it
+        while pending:                                   # also on an exception: the queued images are complete work, keep them
             try:
-                fold(sweep.finish(pending[0]), pending[1])
+                finish_oldest()
             except Exception:
                 if failed is None:                       # nothing else went wrong: this IS the error
                     raise
-                # a device error already in flight makes the fold fail too: the original exception is the one to report
+                break                                    # a device error already in flight makes the fold fail too: report the original
     return (*reduce_counters(st.sums, st.used, dev, world=world), st.attr_time)
 
 

@@ -201,6 +201,14 @@ r0 = np.random.RandomState(100)
 np.testing.assert_array_equal(g, (r0.rand(6, 8, 8) < 0.5).astype(np.uint8))
 np.testing.assert_array_equal(s, r0.randint(0, 28, (6, 2)).astype(np.int32))
 assert g.dtype == np.uint8 and s.dtype == np.int32 and c.tolist() == [28, 28]
+# (2b) a draw held as torch tensors (rise.draw_masks_on_device's kind) goes through the same ONE broadcast and comes back as tensors
+tm = (torch.from_numpy(masks[0].copy()), torch.from_numpy(masks[1].copy()), masks[2])
+calls.clear()
+dist.broadcast = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+tg, ts, tc = xd.broadcast_masks(tm, device)
+dist.broadcast = real
+assert len(calls) == 1 and torch.is_tensor(tg) and torch.is_tensor(ts) and tg.dtype == torch.uint8 and ts.dtype == torch.int32
+np.testing.assert_array_equal(tg.numpy(), g); np.testing.assert_array_equal(ts.numpy(), s); assert tc.tolist() == [28, 28]
 # (3) partial-map all-reduce
 part = torch.full((4, 4), float(rank + 1), dtype=torch.float64)
 assert float(xd.all_reduce_sum(part)[0, 0]) == 3.0

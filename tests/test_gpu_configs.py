@@ -104,6 +104,43 @@ def test_config2_benched_composition_two_images_per_pass(resnet):
         np.testing.assert_array_equal(streamed[i].cpu().numpy(), out[i].cpu().numpy())
 
 
+def test_classifier_passes_on_several_streams_are_bit_identical_to_one_stream(resnet):
+    """`streams=3` queues consecutive classifier passes (IG), consecutive mask batches (RISE) and consecutive images (the sweep)
+    round-robin on three HIP streams.  The kernels and their shapes do not change and the work items write disjoint rows, so with
+    deterministic solvers every result must equal the one-stream run BIT FOR BIT -- a race would show here."""
+    from xai_engine.ig import ig_batch
+    from xai_engine.rise import rise, draw_masks
+    from xai_engine.sweep import sweep_images, get_CNN_attr, KEYS
+    xs = torch.cat([_image(30 + i) for i in range(5)]).to(DEV)
+    with torch.no_grad():
+        ts = resnet(xs).argmax(1)
+    for kw in (dict(alpha_star=1), dict(alpha_star=1, buffered=True), dict(alpha_star=.9)):
+        one = ig_batch(xs, resnet, ts, steps=50, images_per_pass=1, want_abs=True, **kw)
+        for n in (2, 3):
+            many = ig_batch(xs, resnet, ts, steps=50, images_per_pass=1, want_abs=True, streams=n, **kw)
+            for a, b in zip(one, many):
+                np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    # RISE: 230 masks = 4 batches of 50 and one of 30
+    t = int(ts[0])
+    score = lambda b: torch.softmax(resnet(b), 1)[:, t]                                        # noqa: E731
+    np.random.seed(7)
+    masks = draw_masks((224, 224), 230, 8, 0.5)
+    r1 = rise(resnet, xs[:1].cpu(), None, DEV, N=230, s=8, p1=0.5, score_fn=score, batch_size=50, masks=masks)
+    r3 = rise(resnet, xs[:1].cpu(), None, DEV, N=230, s=8, p1=0.5, score_fn=score, batch_size=50, masks=masks, streams=3)
+    np.testing.assert_array_equal(r1.cpu().numpy(), r3.cpu().numpy())
+    # the sweep: five images, IG + ten metrics each; per-image Counters are folded in image order whatever the stream count
+    td = {"models": [resnet], "img_hw": 224, "batch_size": 50, "device": DEV, "device_maps": True, "attr_func": "ig"}
+    images = [_image(1000 + i) for i in range(5)]
+    attr_fn = lambda x, tg: get_CNN_attr(x, None, tg, td)                                      # noqa: E731
+    s1, used1, t1 = sweep_images(images, resnet, DEV, attr_fn, img_hw=224, batch_size=50)
+    s3, used3, t3 = sweep_images(images, resnet, DEV, attr_fn, img_hw=224, batch_size=50, streams=3)
+    assert used1 == used3 == 5
+    for k in KEYS:
+        assert s1[k] == s3[k], (k, s1[k], s3[k])
+    # attribution seconds are HIP-event times of finished attributions now (ADVICE r2): a 50-step IG of ResNet-50 takes >= 8 ms on this part
+    assert 5 * 0.008 < t1 < 5 * 0.2 and 5 * 0.008 < t3 < 5 * 0.5, (t1, t3)
+
+
 def test_config3_rise_resnet50_200_masks(resnet):
     """configs[2]: RISE on ResNet-50 (200 of the 8000 masks; the mask range split of the multi-GPU run is exercised too)."""
     from xai_engine.rise import rise, draw_masks

@@ -654,16 +654,30 @@ def _bench(*flags, ranks=1):
 def test_bench_contract_line_with_one_and_two_ranks():
     """bench.py's N > 1 control flow (launcher, barrier, max-over-ranks, rank-0 print) rehearsed on the one GPU of the test box:
     two ranks share cuda:0 over gloo (XAI_DIST_BACKEND / XAI_FORCE_DEVICE -- never set by the driver)."""
-    small = ("--steps", "1", "--warmup", "1", "--images", "4", "--no-cpu-baseline", "--miopen-db", "0")
+    small = ("--steps", "1", "--warmup", "1", "--images", "4", "--no-cpu-baseline", "--strong-images", "4")
     one, _ = _bench(*small, ranks=1)
     two, _ = _bench(*small, ranks=2)
     for line, n in ((one, 1), (two, 2)):
         assert line["n_gpus"] == n and line["steps"] == 1 and line["warmup"] == 1 and line["scaling"] == "weak"
         assert line["unit"] == "attributions/s" and line["dtype"] == "f32" and line["vs_baseline"] is None
         assert line["config"]["images_per_gpu"] == 4 and "workload" in line["config"]
+        # the headline is the parity configuration: deterministic solvers, immediate mode, one image per pass, three streams
+        assert line["config"]["mode"] == "parity" and line["config"]["images_per_pass"] == 1 and line["config"]["streams"] == 3
+        assert line["config"]["miopen"] == "immediate mode, deterministic solvers only"
+        assert line["parity_mode"]["is_headline"] is True and line["parity_mode"]["value"] == line["value"]
         rf = line["roofline"]
         assert rf["bound"] == "hbm" and rf["kernel"] == "xai_ig_accum_f32" and 0 < rf["frac"] < 1 and "traffic_source" in rf
         assert abs(line["value"] - n * 4 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]        # whole-job aggregate
+        assert line["single_stream"]["streams"] == 1 and line["single_stream"]["value"] > 0
+        assert line["reference_api"]["serial"]["value"] > 0 and line["reference_api"]["on_streams"]["streams"] == 3
+        st = line["sweep_strong"]                                          # the SAME 4-image list whatever the rank count
+        assert st["scaling"] == "strong" and st["images"] == st["images_used"] == 4 and abs(st["value"] - 4 / st["seconds"]) <= 1e-9
+    for k, v in one["sweep_strong"]["metric_means"].items():               # deterministic solvers: only the order of the final sum differs
+        assert abs(v - two["sweep_strong"]["metric_means"][k]) <= 1e-9, (k, v, two["sweep_strong"]["metric_means"][k])
+    tm = one["throughput_mode"]                                            # measured by a child process at N = 1 only
+    assert "error" not in tm, tm
+    assert tm["images_per_pass"] == 2 and tm["miopen"] == "find mode with shipped find-db" and tm["value"] > 0
+    assert "throughput_mode" not in two and two["unfused_classifier"] is None and one["unfused_classifier"]["value"] > 0
     assert "cpu_baseline" not in two
     # two ranks on ONE card: the aggregate can only be about what one rank gets alone (one 4-image step each: a loose band)
     assert 0.25 <= two["value"] / one["value"] <= 2.5, (one["value"], two["value"])
