@@ -25,7 +25,7 @@ reports it as `throughput_mode`.
 `--workload sweep` (opt-in; the driver's contract line is the default `ig` workload) measures north_star's scaling
 target instead: the insertion/deletion sweep of BASELINE config 5 over ONE fixed list of `--sweep-images` synthetic images
 (strong scaling: image i belongs to rank i % world, the list does not grow with N), every image attributed with each of
-`--sweep-methods` and pushed through the ten metrics (224 steps each); one 88-byte all-reduce per method; value = images/s.
+`--sweep-methods` and pushed through the ten metrics (224 steps each); one 96-byte all-reduce per method; value = images/s.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline        the IG accumulation kernel (xai_ig_accum_f32): algorithmic bytes per launch ((S+2)*4N per image, SURVEY
@@ -38,7 +38,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
   throughput_mode `--mode throughput` measured by a child process (N = 1)
   sweep_strong    north_star's scaling target measured by the SAME command: a FIXED list of --strong-images synthetic images
                   (it does not grow with N; image i -> rank i % N), IG + the ten insertion/deletion metrics (224 steps each)
-                  per image, one 88-byte all-reduce; images/s = list length / max-over-ranks time
+                  per image, one 96-byte all-reduce; images/s = list length / max-over-ranks time
   cpu_baseline    the CPU oracle (oracle/ig.py, a port of the reference's IG) on the host cores,
                   a bounded sample (four attributions), rank 0 at N=1 only
 `--lean` skips every side leg (single_stream ... cpu_baseline).
@@ -205,13 +205,13 @@ def run_sweep_workload(args, model, dev, rank, world, prep, miopen_mode, fence, 
                                    f"(seeded random weights), methods {methods}, 224 perturbation steps, batch 50; one step = the whole list",
                        "images": n, "methods": methods, "image_method_pairs_per_s": n * len(methods) * args.steps / dt, "streams": args.streams,
                        "mode": args.mode, "warmup_step": f"a {2 * world}-image sweep per method (not the full list)", "classifier_prep": prep,
-                       "miopen": miopen_mode, "parallelism": f"image i -> rank i % {world}; one all-reduce(SUM) of 11 fp64 (88 B) per method"},
+                       "miopen": miopen_mode, "parallelism": f"image i -> rank i % {world}; one all-reduce(SUM) of 12 fp64 (96 B) per method"},
             "metric_means": means}), flush=True)
 
 
 def sweep_strong_leg(n_images, model, dev, rank, world, fence, max_over_ranks, streams):
     """Strong-scaling leg of the default line: IG (50 steps) + the ten insertion/deletion numbers of every image of ONE fixed list,
-    image i on rank i % world, one all-reduce(SUM) of 11 fp64.  Returns the object for the JSON line (the same on every rank)."""
+    image i on rank i % world, one all-reduce(SUM) of 12 fp64.  Returns the object for the JSON line (the same on every rank)."""
     from xai_engine.sweep import sweep_images, get_CNN_attr, KEYS
     td = {"models": [model], "img_hw": H, "batch_size": 50, "device": str(dev), "device_maps": True, "attr_func": "ig"}
 
@@ -228,7 +228,7 @@ def sweep_strong_leg(n_images, model, dev, rank, world, fence, max_over_ranks, s
     return {"value": n_images / dt, "unit": "images/s", "images": n_images, "seconds": dt, "scaling": "strong", "streams": streams,
             "workload": f"insertion/deletion sweep over a fixed list of {n_images} synthetic 3x224x224 images (seeds 1000..): IG 50 steps + ten "
                         "metrics x 224 perturbation steps per image, batch 50 (BASELINE config 5 restricted to one method)",
-            "parallelism": f"image i -> rank i % {world}; one all-reduce(SUM) of 11 fp64 (88 B)", "images_used": used,
+            "parallelism": f"image i -> rank i % {world}; one all-reduce(SUM) of 12 fp64 (96 B)", "images_used": used,
             "metric_means": {k: total[k] / max(used, 1) for k in KEYS}}
 
 

@@ -9,7 +9,7 @@ contract line is bench.py; this script produces the supporting numbers kept unde
   2  IG / Left-IG through the reference's one-image API (bench.py measures the batched path)
   3  RISE, N masks, ResNet-50, masks sharded over ranks (masks/s; one all-reduce of the partial map)
   4  IG 50 steps on ViT-B/16 (hooked), batch 25 + attention-space IG 20 steps
-  5  insertion/deletion sweep, images sharded over ranks (images/s; one 88-byte all-reduce)
+  5  insertion/deletion sweep, images sharded over ranks (images/s; one 96-byte all-reduce)
   6  RISE-family maskers on ViT-B/16: ViT-CX and TIS end to end, one image (latency)
 One JSON line per configuration on rank 0.
 """
@@ -218,8 +218,8 @@ def main():
             extra["max_abs_diff_fused_vs_8_runs"] = max(abs(fused[k] - eight[k]) for k in KEYS)
         emit({"config": 5, "workload": f"IG attribution + 10 ins/del metrics (224 steps), ResNet-50, {n_img} synthetic images, "
                                        f"image-sharded x{world}", "images": used, "seconds": dt, "images_per_s": used / dt,
-              "attr_seconds_rank0": attr_t, "metric_means": {k: total[k] / used for k in KEYS}, "n_gpus": world,
-              "collective": "1 all_reduce(SUM) of 11 fp64 = 88 B", **extra})
+              "attr_seconds_all_ranks": attr_t, "metric_means": {k: total[k] / used for k in KEYS}, "n_gpus": world,
+              "collective": "1 all_reduce(SUM) of 12 fp64 = 96 B", **extra})
 
     if 6 in want:
         from xai_engine.vit_cx import ViT_CX

@@ -54,6 +54,68 @@ def density_curve(seg_f32, total_f32, inserting):
     return dens
 
 
+def shape_constrained_fit(y, mode, return_multipliers=False):
+    """`special_version=True` of MASMetric.single_run (reference MASTestFunctions.py:311-350): the least-squares curve x closest to
+    the normalised response y with x[0] = y[0], x[-1] = y[-1], 0 <= x <= 1 and non-negative second differences for 'del' (convex),
+    non-positive ones for 'ins' (concave); for 'morf' / 'lerf' the reference's shape rows stay zero, leaving the box and the end points.
+
+    The reference hands the dense QP (225 variables, 673 inequality rows) to cvxopt's interior-point solver (not importable here: parity
+    unpinned; its answer is the optimum to its default tolerances, ~1e-7).  The optimum is unique -- the objective is strictly convex --
+    so it is computed exactly instead: end points eliminated, the least-distance problem  min |z - y_mid|  s.t.  G z <= h  solved through
+    its non-negative least-squares dual (Lawson & Hanson's LDP: an active-set method, finite, exact up to rounding), then the active set it
+    finds is re-solved as an equality-constrained problem (one Cholesky-sized solve) and the Karush-Kuhn-Tucker conditions of the ORIGINAL
+    problem are checked; tests/test_cpu_host.py holds the KKT residual to 1e-9.  Host-only float64 arithmetic on <= 225 numbers.
+    A response containing NaN (the blurred / black image scored exactly like the input: 0/0 in the normalisation) is returned
+    unchanged, so that the reference's NaN guard downstream (:363-368) takes over as it does without special_version."""
+    from scipy.optimize import nnls
+    y = np.asarray(y, dtype=np.float64)
+    n = y.shape[0]
+    x = y.copy()
+    if not np.isfinite(y).all():
+        return (x, None) if return_multipliers else x
+    if n <= 2 or mode not in ("del", "ins"):
+        x[1:-1] = np.clip(y[1:-1], 0.0, 1.0)                # box + fixed end points: separable
+        return (x, None) if return_multipliers else x
+    m = n - 2
+    sgn = 1.0 if mode == "del" else -1.0
+    # shape rows over x = (y0, z, y_end):  sgn * (-x[i] + 2 x[i+1] - x[i+2]) <= 0,  i = 0 .. n-3, written over z with the end points on the right
+    S = np.zeros((m, m))
+    rhs = np.zeros(m)
+    i = np.arange(m)
+    S[i, i] = 2.0 * sgn                                     # x[i+1] = z[i]
+    S[i[1:], i[1:] - 1] = -sgn                              # x[i]   = z[i-1]   (i >= 1)
+    S[i[:-1], i[:-1] + 1] = -sgn                            # x[i+2] = z[i+1]   (i <= m-2)
+    rhs[0] += sgn * y[0]
+    rhs[-1] += sgn * y[-1]
+    G = np.vstack([-np.eye(m), np.eye(m), S])               # -z <= 0,  z <= 1,  shape
+    h = np.concatenate([np.zeros(m), np.ones(m), rhs])
+    ym = y[1:-1]
+    d = h - G @ ym                                          # G u <= d  for  u = z - ym
+    if (d >= 0).all():                                      # y itself is feasible: it is the optimum
+        return (x, np.zeros(len(h))) if return_multipliers else x
+    # LDP (Lawson & Hanson, ch. 23): (-G) u >= -d;  E = [(-G)^T ; (-d)^T],  f = e_{m+1};  w = argmin_{w >= 0} |E w - f|;  u = -r[:m] / r[m]
+    E = np.vstack([-G.T, -d[None, :]])
+    f = np.zeros(m + 1)
+    f[m] = 1.0
+    w, _ = nnls(E, f, maxiter=20 * E.shape[1])
+    r = E @ w - f
+    if not abs(r[m]) > 1e-14:
+        raise ValueError("special_version: the shape constraints are infeasible for this response (cannot happen for end points in [0, 1])")
+    z = ym - r[:m] / r[m]
+    lam = 2.0 * w / (-r[m])                                  # multipliers of G z <= h for the objective |z - ym|^2
+    # polish on the active set the dual found: z = ym - G_A^T mu with (G_A G_A^T) mu = G_A ym - h_A
+    act = np.nonzero(w > 0)[0]
+    if act.size:
+        GA, hA = G[act], h[act]
+        mu, *_ = np.linalg.lstsq(GA @ GA.T, GA @ ym - hA, rcond=None)
+        zp = ym - GA.T @ mu
+        if (mu >= -1e-12).all() and (G @ zp - h <= 1e-12).all():
+            z, lam = zp, np.zeros(len(h))
+            lam[act] = 2.0 * np.maximum(mu, 0.0)
+    x[1:-1] = z
+    return (x, lam) if return_multipliers else x
+
+
 def mas_correct(normalised, density, mode):
     """Alignment penalty, clip, min-max rescale, NaN guard (reference MASTestFunctions.py:352-368)."""
     n = len(normalised)

@@ -2,7 +2,7 @@
 "gloo" for the CPU rehearsal tests).  The hot path shards embarrassingly:
 
   images      -> sweep.sweep_images: round-robin image ownership, ONE all-reduce(SUM) of an
-                 11-element fp64 vector (88 B) at the end            [evaluatePerturbation.py:594-618]
+                 12-element fp64 vector (96 B) at the end            [evaluatePerturbation.py:594-618]
   RISE masks  -> rise_sharded: contiguous mask ranges, ONE all-reduce(SUM) of the (H,W) fp64
                  partial map (401 KB at 224x224)                      [generate_emap.py:93-100]
 

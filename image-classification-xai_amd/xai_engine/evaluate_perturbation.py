@@ -50,6 +50,11 @@ def build_parser():
     p.add_argument("--batch_size", type=int, default=None, help="images per classifier pass in the metrics (`max_batch_size`); default: the "
                    "reference's value for the model (50 / 25).  Larger batches are faster (ResNet-50: 98 ms per image-sweep at 50, 91 at 112, "
                    "88 at 225) and move the ten numbers by <= 3e-6 (profiles/r02_exp_sweep_batch.txt)")
+    p.add_argument("--reference_counter", action="store_true", help="fold the images' results exactly like the reference's `pert_result_counter "
+                   "+= ...` (evaluatePerturbation.py:594-596: a key whose running sum is <= 0 is dropped) and write only the surviving CSV rows "
+                   "(:612-615).  Default: plain sums, always ten rows")
+    p.add_argument("--streams", type=int, default=3, help="HIP streams consecutive images are queued on (fused sweep; results are bit-identical "
+                   "to 1 with the default deterministic solvers)")
     p.add_argument("--out_dir", type=str, default="pert_test_results")
     p.add_argument("--checkpoint", type=str, default=None, help="path prefix for per-rank resume files (the reference loses a crashed run)")
     return p
@@ -83,9 +88,10 @@ def main(argv=None):
                     "image_count": args.image_count, "device": str(device), "class_map_path": args.class_map,
                     "weights_path": args.weights or "", "num_patches": num_patches}
     total, used, _ = harness.evaluate_perturbation(testing_dict, rank=rank, world=world, fused=not args.eight_runs, out_dir=args.out_dir,
-                                                     checkpoint=args.checkpoint)
+                                                     checkpoint=args.checkpoint, streams=args.streams, reference_counter=args.reference_counter)
     if rank == 0:
-        print(f"{used} images; means: " + ", ".join(f"{k}={total[k] / max(used, 1):.6f}" for k in total))
+        fold = "reference Counter += (keys with a running sum <= 0 dropped)" if args.reference_counter else "plain sums"
+        print(f"{used} images; {fold}; means: " + ", ".join(f"{k}={total[k] / max(used, 1):.6f}" for k in total))
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -146,10 +146,15 @@ def select_images(testing_dict, correctly_classified=None, names=None, rank=0, w
         if quota.full:
             break
         part = candidates[lo:lo + step]
-        table = torch.zeros((len(part), 3), dtype=torch.int32)                 # [is_rgb, sane, class + 1] per candidate
+        table = torch.zeros((len(part), 3), dtype=torch.int32)                 # [is_rgb (-1: could not be judged), sane, class + 1] per candidate
+        errors = {}
         for j in range(rank, len(part), world):
-            rgb, sane, target = _verdict(model, blur, dev, os.path.join(root, part[j]), img_hw, mean, std)
-            table[j] = torch.tensor([int(rgb), int(sane), target + 1], dtype=torch.int32)
+            try:
+                rgb, sane, target = _verdict(model, blur, dev, os.path.join(root, part[j]), img_hw, mean, std)
+                table[j] = torch.tensor([int(rgb), int(sane), target + 1], dtype=torch.int32)
+            except Exception as e:                                               # unreadable / corrupt file: recorded in the table, never raised
+                table[j] = torch.tensor([-1, 0, 0], dtype=torch.int32)          # here -- the other ranks are on their way into the collective
+                errors[j] = e
         if world > 1:
             from . import dist as _xd
             import torch.distributed as _dist
@@ -159,7 +164,13 @@ def select_images(testing_dict, correctly_classified=None, names=None, rank=0, w
                 table = _xd.all_reduce_sum(table.to(dev)).cpu()
             else:
                 table = _xd.all_reduce_sum(table)
-        for name, (rgb, sane, tplus) in zip(part, table.tolist()):            # order-dependent part, replicated, host only
+        for j, (name, (rgb, sane, tplus)) in enumerate(zip(part, table.tolist())):   # order-dependent part, replicated, host only
+            if quota.full:
+                break                # the reference stops READING files here (:522-524): a bad file past this point never mattered
+            if rgb < 0:
+                # every rank replays the same table, so every rank raises here, with the file's name -- no rank is left in a collective
+                why = f": {type(errors[j]).__name__}: {errors[j]}" if j in errors else f" (judged on rank {j % world})"
+                raise RuntimeError(f"select_images: {os.path.join(root, name)} could not be read or classified{why}") from errors.get(j)
             quota.offer(name, bool(rgb), bool(sane), tplus - 1)
     chosen = quota.chosen
     images = SelectedImages(root, [c[0] for c in chosen], img_hw, mean, std)
@@ -168,11 +179,14 @@ def select_images(testing_dict, correctly_classified=None, names=None, rank=0, w
     return [(name, images[i], target) for i, (name, target) in enumerate(chosen)]
 
 
-def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pert_test_results", checkpoint=None):
+def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pert_test_results", checkpoint=None, streams=1,
+                          reference_counter=False):
     """Selection pre-pass, attribution + ten metrics per selected image (sharded over ranks), CSV on
     rank 0.  `testing_dict` has the reference's keys (:705-718): models, imagenet_dataset, img_hw,
     batch_size, attr_func, model_name, image_count, device (+ optional normalize=(mean, std),
-    class_map_path)."""
+    class_map_path).  `reference_counter`: fold the images' Counters and write the CSV exactly as the reference does
+    (`+=` in file order drops keys with a running sum <= 0, only surviving keys are written; :594-596,:612-615) -- the
+    default is plain sums and always ten rows.  `streams`: HIP streams consecutive images are queued on."""
     t_start = time.time()
     cc = None
     path = testing_dict.get("class_map_path")
@@ -192,11 +206,13 @@ def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pe
 
     identity = _sweep.sweep_identity(attr_func=testing_dict["attr_func"], model_name=testing_dict["model_name"],
                                      image_count=testing_dict["image_count"], files="|".join(names),
-                                     weights=testing_dict.get("weights_path", ""))
+                                     weights=testing_dict.get("weights_path", ""), fold="reference" if reference_counter else "sums")
     total, used, attr_time = _sweep.sweep_images(images, model, dev, attr_fn, img_hw=testing_dict["img_hw"],
                                                  batch_size=testing_dict["batch_size"], fused=fused, rank=rank, world=world,
-                                                 testing_dict=testing_dict, checkpoint=checkpoint, identity=identity)
+                                                 testing_dict=testing_dict, checkpoint=checkpoint, identity=identity, streams=streams,
+                                                 reference_counter=reference_counter)
     if rank == 0 and used:
         name = f'{testing_dict["attr_func"]}_{testing_dict["image_count"]}_images.csv'
-        _sweep.write_csv(os.path.join(out_dir, testing_dict["model_name"], name), total, used, attr_time, time.time() - t_start)
+        _sweep.write_csv(os.path.join(out_dir, testing_dict["model_name"], name), total, used, attr_time, time.time() - t_start,
+                         reference_counter=reference_counter)
     return total, used, names

@@ -185,8 +185,6 @@ class MASMetric(_PerturbationMetric):
 
     def single_run(self, img_tensor, saliency_map, device, patch_mask=None, max_batch_size=50, special_version=False,
                    return_embeddings=False, CLIP_test_info=None, *, salient_order=None):
-        if special_version:
-            raise NotImplementedError("special_version (cvxopt QP smoothing of the curve) is outside the accelerated path")
         if return_embeddings and CLIP_test_info is not None:
             raise NotImplementedError("return_embeddings reads model.blocks[i].get_block_out(): hooked ViT classifiers only, as in the reference")
         r = self._run(img_tensor, saliency_map, device, patch_mask, max_batch_size, CLIP_test_info, want_density=True,
@@ -196,6 +194,10 @@ class MASMetric(_PerturbationMetric):
         if CLIP_test_info is not None:
             r["entropy"] = np.ones(r["n_steps"] + 1)        # the reference's CLIP branch never fills it (:143-159,:277-281)
         norm = curves.monotone_normalise(r["response"], r["baseline_pred"], r["original_pred"], falling=(self.mode != 'ins'))
+        if special_version:
+            # the convex ('del') / concave ('ins') least-squares smoothing of the normalised response (:311-350), solved exactly on the
+            # host instead of by cvxopt's interior-point iteration (curves.shape_constrained_fit; parity unpinned: cvxopt is absent)
+            norm = curves.shape_constrained_fit(norm, self.mode)
         corrected = curves.mas_correct(norm, r["density"], self.mode)
         return r["n_steps"] + 1, corrected, r["entropy"], r["density"], norm
 

@@ -1,7 +1,8 @@
 """Harness counterpart of XAI_Survey/evaluations/evaluatePerturbation.py for the accelerated
 methods: attribution dispatch (get_CNN_attr :82-181), the ten perturbation numbers of one image
 (run_perturbation :448-497), and the image sweep with its Counter sum / CSV (:499-620), image-
-sharded over ranks with one RCCL all-reduce at the end.
+sharded over ranks with one RCCL all-reduce at the end.  The sums are plain sums by default; `reference_counter=True` reproduces
+the reference's `Counter +=` fold and CSV loop exactly (keys with a running sum <= 0 vanish, :594-596,:612-615).
 
 `run_perturbation` drives the eight metric objects exactly like the reference.
 `PerturbationSweep` computes the same ten numbers from the THREE distinct image sequences the
@@ -252,17 +253,55 @@ def shard_indices(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-def reduce_counters(local_sum, n_local, device=None, group=None, world=None):
-    """One all-reduce(SUM) of [10 metric sums, images used] in fp64 (88 bytes) -> global Counter, count.
-    `world=1` (a caller that did not shard) skips the collective even inside an initialised job."""
+def reduce_counters(local_sum, n_local, device=None, group=None, world=None, attr_seconds=None):
+    """One all-reduce(SUM) of [10 metric sums, images used, seconds in attribution] in fp64 (96 bytes) -> global Counter, count
+    (and the summed seconds when `attr_seconds` is given).  `world=1` (a caller that did not shard) skips the collective even
+    inside an initialised job."""
     import torch.distributed as dist
-    vec = torch.tensor([float(local_sum.get(k, 0.0)) for k in KEYS] + [float(n_local)], dtype=torch.float64)
+    vec = torch.tensor([float(local_sum.get(k, 0.0)) for k in KEYS] + [float(n_local), float(attr_seconds or 0.0)], dtype=torch.float64)
     if world != 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if dist.get_backend(group) == "nccl":
             vec = vec.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
         vec = vec.cpu()
-    return Counter({k: float(vec[i]) for i, k in enumerate(KEYS)}), int(round(float(vec[-1])))
+    out = (Counter({k: float(vec[i]) for i, k in enumerate(KEYS)}), int(round(float(vec[len(KEYS)]))))
+    return out if attr_seconds is None else out + (float(vec[len(KEYS) + 1]),)
+
+
+def replay_reference_counter(rows):
+    """The reference's running Counter over per-image results in FILE ORDER (evaluatePerturbation.py:593-596): the first image's
+    Counter is taken as it is, every later one is folded in with `+=` -- collections.Counter.__iadd__ adds and then deletes every
+    key whose running sum is not > 0 (a zero AIC sum, a negative Spearman sum, a NaN), and a deleted key that comes back starts from
+    nothing and sits at the end.  rows: iterable of 10-vectors in KEYS order.  Uses the standard library's Counter itself, so the
+    semantics are the reference's by construction (pinned by tests/golden/sweep_counter.npz)."""
+    total = None
+    for r in rows:
+        c = Counter({k: float(v) for k, v in zip(KEYS, r)})
+        if total is None:
+            total = c
+        else:
+            total += c
+    return total if total is not None else Counter()
+
+
+def gather_rows(local_rows, n_items, device=None, group=None, world=None, attr_seconds=0.0):
+    """All ranks' per-image 10-vectors as one (n_items, 10) fp64 matrix plus a used-flag column, by ONE all-reduce(SUM) of the
+    zero-padded (n_items + 1, 11) matrix (every image is owned by exactly one rank, so the rows are disjoint; 88 B x images --
+    88 KB for the 1000-image sweep; the extra row carries the seconds in attribution).  local_rows: {global index: 10-vector}.
+    -> (rows (n_items, 10) float64, used (n_items,) bool, summed attribution seconds)."""
+    import torch.distributed as dist
+    mat = torch.zeros((n_items + 1, len(KEYS) + 1), dtype=torch.float64)
+    for i, r in local_rows.items():
+        mat[int(i), :len(KEYS)] = torch.as_tensor(np.asarray(r, dtype=np.float64))
+        mat[int(i), len(KEYS)] = 1.0
+    mat[n_items, 0] = float(attr_seconds)
+    if world != 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "nccl":
+            mat = mat.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(mat, op=dist.ReduceOp.SUM, group=group)
+        mat = mat.cpu()
+    m = mat.numpy()
+    return m[:n_items, :len(KEYS)].copy(), m[:n_items, len(KEYS)] > 0.5, float(m[n_items, 0])
 
 
 def sweep_identity(**facts):
@@ -302,6 +341,7 @@ class SweepState:
         self.used = 0            # images folded into `sums`
         self.next_pos = 0        # position in this rank's shard list
         self.attr_time = 0.0
+        self.rows = {}           # reference_counter mode: {global image index: that image's ten numbers}
 
     @staticmethod
     def path_for(prefix, rank, world):
@@ -313,7 +353,8 @@ class SweepState:
         tmp = path + ".tmp"
         with open(tmp, "w") as f:
             json.dump(dict(n_items=self.n_items, rank=self.rank, world=self.world, identity=self.identity, sums=self.sums,
-                           used=self.used, next_pos=self.next_pos, attr_time=self.attr_time), f)
+                           used=self.used, next_pos=self.next_pos, attr_time=self.attr_time,
+                           rows={str(i): [float(v) for v in r] for i, r in self.rows.items()}), f)
         os.replace(tmp, path)
 
     @classmethod
@@ -331,11 +372,12 @@ class SweepState:
                     "Use another --checkpoint prefix or delete the file.")
             st.sums = {k: float(d["sums"][k]) for k in KEYS}
             st.used, st.next_pos, st.attr_time = int(d["used"]), int(d["next_pos"]), float(d["attr_time"])
+            st.rows = {int(i): [float(v) for v in r] for i, r in d.get("rows", {}).items()}
         return st
 
 
 def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fused=True, rank=0, world=1, testing_dict=None,
-                 checkpoint=None, checkpoint_every=25, identity=None, streams=1):
+                 checkpoint=None, checkpoint_every=25, identity=None, streams=1, reference_counter=False):
     """Attribution + ten perturbation numbers for every image this rank owns; returns the
     globally reduced (Counter of sums, images used, seconds in attribution).
     images: sequence of (1,C,H,W) CPU/device tensors (already selected -- the order-dependent
@@ -346,6 +388,11 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     of another split or identity raises CheckpointMismatch.  `identity`: string from `sweep_identity(...)` naming
     what the caller's attr_fn / image list are (the harness passes attr_func, model name, file-name hash, ...); the
     flow (fused / eight runs), geometry and a fingerprint of the classifier's weights are always added here.
+    `reference_counter`: fold the per-image results the way the reference does (`replay_reference_counter`: Counter `+=` in file
+    order, keys with a running sum <= 0 dropped) instead of plain sums.  The fold is order-dependent, so every rank keeps its
+    images' ten numbers, ONE all-reduce of the zero-padded (images, 11) matrix hands every rank all of them (`gather_rows`), and
+    the replay runs over them in file order -- the same Counter for every world size.  The Counter returned then holds only
+    the surviving keys, in the reference's order; `write_csv(..., reference_counter=True)` writes exactly those rows.
     `streams` > 1 (fused flow): consecutive images are queued round-robin on that many HIP streams -- attribution, ranking and the
     three step sequences of one image form a serial chain of mostly small or low-occupancy launches, so the chains of `streams`
     images overlap on the chip.  Every image still runs the same kernels on the same shapes and the per-image Counters are folded
@@ -366,6 +413,8 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     def fold(c, pos):
         for k in KEYS:                                   # plain sums: see DESIGN.md on the reference's Counter `+=`
             st.sums[k] += float(c[k])
+        if reference_counter:
+            st.rows[mine[pos]] = [float(c[k]) for k in KEYS]
         st.used += 1
         st.next_pos = pos + 1
         if checkpoint and (st.next_pos % checkpoint_every == 0 or st.next_pos == len(mine)):
@@ -430,15 +479,24 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
                 if failed is None:                       # nothing else went wrong: this IS the error
                     raise
                 break                                    # a device error already in flight makes the fold fail too: report the original
-    return (*reduce_counters(st.sums, st.used, dev, world=world), st.attr_time)
+    if reference_counter:
+        if len(st.rows) != st.used:
+            raise CheckpointMismatch("this checkpoint was written without reference_counter: it holds sums only, not the per-image "
+                                     "numbers the reference's order-dependent fold needs; start again with another --checkpoint prefix")
+        rows, flags, attr_seconds = gather_rows(st.rows, len(images), dev, world=world, attr_seconds=st.attr_time)
+        return replay_reference_counter(rows[flags]), int(flags.sum()), attr_seconds
+    return reduce_counters(st.sums, st.used, dev, world=world, attr_seconds=st.attr_time)
 
 
-def write_csv(path, counter_sum, images_used, attr_time, total_time):
-    """rows `key,mean` for the ten metrics + the two runtime rows (reference :606-618)."""
+def write_csv(path, counter_sum, images_used, attr_time, total_time, reference_counter=False):
+    """rows `key,mean` for the metrics + the two runtime rows (reference :606-618).
+    Default: always the ten keys in KEYS order, plain sums / images.  `reference_counter=True`: `counter_sum` is the Counter of
+    `sweep_images(..., reference_counter=True)` and the loop is the reference's (:612-615) -- only the keys that survived its
+    `+=`, in the Counter's own order."""
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     with open(path, "w") as f:
         w = csv.writer(f)
-        for k in KEYS:
+        for k in (counter_sum if reference_counter else KEYS):
             w.writerow([k, str(counter_sum[k] / images_used)])
         w.writerow(["Attr Avg Runtime", str(attr_time / images_used)])
         w.writerow(["Total Runtime", str(total_time)])

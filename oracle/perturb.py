@@ -169,8 +169,58 @@ def _probe(logits_fn, img):
 
 
 # ------------------------------------------------------------------ the five metrics
-def mas(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50, order=None):
-    """MASMetric.single_run (special_version=False, no CLIP) [MASTestFunctions.py:72-385].
+def special_version_problem(y, mode):
+    """The dense QP of special_version=True exactly as the reference assembles it [MASTestFunctions.py:311-345]:
+    minimise 1/2 x^T Q x + c^T x  s.t.  G x <= h,  A x = b,  with Q = 2 I, c = -2 y, G = [-I; I; shape rows], h = [0; 1; 0],
+    A picking the two end points.  Shape rows: (-1, 2, -1) for 'del', (1, -2, 1) for 'ins', all-zero for every other mode."""
+    y = np.asarray(y, dtype=np.float64)
+    n = len(y)
+    Q = 2 * np.eye(n)
+    c = -2 * y
+    A_ineq = np.zeros((n - 2, n))
+    rows = np.arange(n - 2)
+    if mode == "del":
+        A_ineq[rows, rows], A_ineq[rows, rows + 1], A_ineq[rows, rows + 2] = -1, 2, -1
+    elif mode == "ins":
+        A_ineq[rows, rows], A_ineq[rows, rows + 1], A_ineq[rows, rows + 2] = 1, -2, 1
+    G = np.vstack([-np.eye(n), np.eye(n), A_ineq])
+    h = np.hstack([np.zeros(n), np.ones(n), np.zeros(n - 2)])
+    A = np.zeros((2, n))
+    A[0, 0] = 1
+    A[1, -1] = 1
+    b = np.array([y[0], y[-1]])
+    return Q, c, G, h, A, b
+
+
+def special_version_qp(y, mode):
+    """Solve `special_version_problem` with a general-purpose solver (SciPy's SLSQP with exact derivatives) -- independent of the
+    product's active-set solution.  The reference calls cvxopt.solvers.qp [MASTestFunctions.py:348-349], which is not
+    importable here (parity unpinned); both aim at the unique optimum of the same strictly convex problem."""
+    from scipy.optimize import minimize
+    Q, c, G, h, A, b = special_version_problem(y, mode)
+    y = np.asarray(y, dtype=np.float64)
+    res = minimize(lambda x: 0.5 * x @ Q @ x + c @ x, np.clip(y, 0, 1), jac=lambda x: Q @ x + c, method="SLSQP",
+                   constraints=[{"type": "ineq", "fun": lambda x: h - G @ x, "jac": lambda x: -G},
+                                {"type": "eq", "fun": lambda x: A @ x - b, "jac": lambda x: A}],
+                   options={"maxiter": 1000, "ftol": 1e-15})
+    return res.x
+
+
+def kkt_residual(x, y, mode):
+    """How far x is from satisfying the Karush-Kuhn-Tucker conditions of `special_version_problem` (necessary and sufficient: the
+    problem is convex): max of the primal violations and of the stationarity residual |Qx + c + G^T lam + A^T nu| minimised over
+    lam >= 0 supported on the constraints active at x (within 1e-9) and nu free -- itself a non-negative least-squares problem."""
+    from scipy.optimize import nnls
+    Q, c, G, h, A, b = special_version_problem(y, mode)
+    primal = max(float(np.max(G @ x - h)), float(np.abs(A @ x - b).max()), 0.0)
+    act = np.nonzero(G @ x - h >= -1e-9)[0]
+    M = np.hstack([G[act].T, A.T, -A.T])
+    _, stat = nnls(M, -(Q @ x + c), maxiter=50 * M.shape[1])
+    return max(primal, float(stat))
+
+
+def mas(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max_batch_size=50, order=None, special_version=False):
+    """MASMetric.single_run (no CLIP) [MASTestFunctions.py:72-385].
     Returns (n_steps+1, corrected_scores, entropy, density_response, normalized_response)."""
     assert mode in ("del", "ins", "lerf", "morf")
     HW = img.shape[-1] * img.shape[-2]
@@ -208,6 +258,8 @@ def mas(logits_fn, img, sal, mode, step_size, substrate_fn, patch_mask=None, max
         dens[i + 1] = dens[i] + sign * (np.sum(flat[g]) / total)
 
     norm = monotone(response, base, orig, falling=(mode != "ins"))
+    if special_version:
+        norm = special_version_qp(norm, mode)
     pen = np.abs(norm - dens)
     corr = norm - pen if mode == "ins" else norm + pen
     corr = corr.clip(0, 1)
@@ -333,3 +385,24 @@ def run_perturbation(logits_fn, img, sal, step_size, blur_fn, max_batch_size=50)
     _, mneg = mono(logits_fn, img, sal, "negative", step_size, zeros, None, max_batch_size)
     return dict(zip(SWEEP_KEYS, (auc(mas_i), auc(mas_d), auc(rise_i), auc(rise_d), auc(aic_i), auc(aic_d),
                                  auc(lerf), auc(morf), mpos, mneg)))
+
+
+def reference_fold(rows):
+    """The reference's running result over the images of a sweep, restated with a plain dict
+    [evaluatePerturbation.py:593-596: `pert_result_counter = run_perturbation(...)` for the first image,
+    `pert_result_counter += run_perturbation(...)` afterwards].  `+=` on a collections.Counter adds the new
+    counts and then deletes every key whose total is not > 0 (zero, negative, NaN); a key deleted earlier starts
+    again from 0 and, being newly inserted, moves to the END of the iteration order the CSV loop (:612-615) follows.
+    rows: per-image 10-vectors in SWEEP_KEYS order, in file order -> (surviving keys in CSV order, their sums)."""
+    total = None
+    for r in rows:
+        c = {k: float(v) for k, v in zip(SWEEP_KEYS, r)}
+        if total is None:
+            total = c                               # first image: taken as is, non-positive entries included
+            continue
+        for k, v in c.items():
+            total[k] = total.get(k, 0) + v
+        for k in [k for k, v in total.items() if not v > 0]:
+            del total[k]
+    total = total or {}
+    return list(total), list(total.values())

@@ -30,6 +30,8 @@ What is pinned (reference file:line in brackets):
   smoothgrad.npz              seeded smoothGrad("IG", ..., vis=True): mean, total_gradients, noisy_imgs [saliencyMethods.py:184-205]
   sweep_small.npz             the 10-key Counter of run_perturbation, driven exactly like
                               XAI_Survey/evaluations/evaluatePerturbation.py:448-497
+  sweep_counter.npz           five images folded with the reference's `pert_result_counter += ...` (:594-596) and written with its CSV
+                              loop (:612-615): keys whose running sum is <= 0 are dropped and re-enter at the end
 The only stubs are inert placeholder modules: `cvxopt` (used by the reference only under
 special_version=True, which is never exercised) and, for the ViT-CX / TIS files, the third-party modules they
 import at module level but never reach on the functions called here (see vitcx_fixture / tis_fixture).
@@ -328,6 +330,73 @@ def sweep_fixture():
     print("sweep_small.npz", dict(zip(KEYS, out["counter_sum"])))
 
 
+def _ten_numbers(model, x, sal, hw, blur):
+    """One image through the eight metric objects, the statements of run_perturbation [evaluatePerturbation.py:448-497]."""
+    from collections import Counter
+    HW, step, bs, dev = hw * hw, hw, 50, "cpu"
+    z = torch.zeros_like
+    with torch.no_grad():
+        _, MAS_ins, _, _, RISE_ins = MAS.MASMetric(model, HW, 'ins', step, blur).single_run(x.clone(), sal, dev, max_batch_size=bs)
+        _, MAS_del, _, _, RISE_del = MAS.MASMetric(model, HW, 'del', step, z).single_run(x.clone(), sal, dev, max_batch_size=bs)
+        _, AIC_ins = AIC.AICMetric(model, HW, 'ins', step, blur).single_run(x.clone(), sal, dev, max_batch_size=bs)
+        _, AIC_del = AIC.AICMetric(model, HW, 'del', step, z).single_run(x.clone(), sal, dev, max_batch_size=bs)
+        _, LERF = PNP.PositiveNegativePerturbation(model, HW, 'lerf', step, z).single_run(x.clone(), sal, dev, max_batch_size=bs)
+        _, MORF = PNP.PositiveNegativePerturbation(model, HW, 'morf', step, z).single_run(x.clone(), sal, dev, max_batch_size=bs)
+        _, MONO_pos = MONO.MonotonicityMetric(model, HW, 'positive', step, blur).single_run(x.clone(), sal, dev, max_batch_size=bs)
+        _, MONO_neg = MONO.MonotonicityMetric(model, HW, 'negative', step, z).single_run(x.clone(), sal, dev, max_batch_size=bs)
+    return Counter({"MAS_ins": MAS.auc(MAS_ins), "MAS_del": MAS.auc(MAS_del), "RISE_ins": MAS.auc(RISE_ins),
+                    "RISE_del": MAS.auc(RISE_del), "AIC_ins": MAS.auc(AIC_ins), "AIC_del": MAS.auc(AIC_del),
+                    "LERF_res": MAS.auc(LERF), "MORF_res": MAS.auc(MORF), "MONO_pos": MONO_pos, "MONO_neg": MONO_neg})
+
+
+def counter_fixture():
+    """What the reference's image loop does with the per-image Counters [evaluatePerturbation.py:594-596,612-615]: the first
+    image's Counter is taken as is, every later one is folded in with `+=` -- collections.Counter.__iadd__, which adds and then
+    DELETES every key whose running sum is not > 0 -- and the CSV loop writes the surviving keys in the Counter's own order, so
+    a key that was dropped and came back sits at the end and has lost its history.  Five images chosen so that this happens:
+    |IG| maps give negative Spearman correlations on this tiny net (images 0, 1, 4), random maps positive ones (2, 3);
+    AIC_ins is 0 for four of the five.  Sequence: MONO_pos / MONO_neg / AIC_ins dropped after image 1, MONO_* back after
+    image 2, AIC_ins back after image 3.  (evaluatePerturbation.py itself cannot be imported here -- clip / captum /
+    torchvision at module import -- so its three statements are driven from this function, on the reference's metric classes
+    and the standard library's Counter.)"""
+    hw, seed = 32, 40
+    model = tiny_model(seed)
+    kern = MAS.gkern(31, 31)
+    blur = lambda t: torch.nn.functional.conv2d(t, kern, padding=15)   # noqa: E731
+    out = dict(**weights_of(model))
+    plan = [(0, "absig"), (2, "absig"), (5, "rand"), (1, "rand"), (4, "absig")]
+    xs, sals = [], []
+    images_used = 0
+    for n, (i, kind) in enumerate(plan):
+        x = randn(500 + 10 * i + 1, 1, 3, hw, hw)
+        if kind == "rand":
+            sal = tie_free_map(500 + 10 * i + 2, hw)
+        else:
+            with torch.no_grad():
+                t = model(x).argmax(1)[0]
+            sal = np.abs(attr.IG(x.clone(), model, 50, 25, 1, 0, "cpu", t).detach().numpy().sum(0)).astype(np.float32)
+            assert len(np.unique(sal)) == sal.size                      # tie-free: the pixel order is the same on every machine
+        xs.append(x.numpy()); sals.append(sal)
+        c = _ten_numbers(model, x, sal, hw, blur)
+        out[f"counter_{n}"] = np.array([float(c[k]) for k in KEYS])
+        if images_used == 0:                                            # :593-596
+            pert_result_counter = c
+        else:
+            pert_result_counter += c
+        images_used += 1
+        out[f"keys_after_{n}"] = np.array(list(pert_result_counter))
+        out[f"values_after_{n}"] = np.array([float(pert_result_counter[k]) for k in pert_result_counter])
+    rows = [[k, str(pert_result_counter[k] / images_used)] for i, k in enumerate(pert_result_counter)]       # :612-615
+    out["x"] = np.concatenate(xs); out["saliency"] = np.stack(sals)
+    out["keys"] = np.array(KEYS)
+    out["csv_keys"] = np.array([r[0] for r in rows]); out["csv_values"] = np.array([r[1] for r in rows])
+    out["images_used"] = np.int64(images_used)
+    np.savez_compressed(os.path.join(HERE, "sweep_counter.npz"), **out)
+    print("sweep_counter.npz", rows)
+    for n in range(len(plan)):
+        print("  after image", n, list(out[f"keys_after_{n}"]))
+
+
 def vit_fixture():
     """Mini hooked ViT of the reference (ViT_ig.py:161-253; 32x32 image, patch 8, dim 32, depth 2,
     4 heads, 10 classes): pixel-space IG through saliencyMethods.IG and attention-space IG through
@@ -517,6 +586,7 @@ if __name__ == "__main__":
     perturb_fixture("perturb_224.npz", 224, 224, 320, 50, keep_images=False, blur_k=(31, 31))
     perturb_fixture("perturb_ties.npz", 32, 32, 330, 10, keep_images=False, ties=True)   # tied map: the reference's own (unstable) order recorded
     sweep_fixture()
+    counter_fixture()
     vit_fixture()
     cam_fixture()
     vitcx_fixture()

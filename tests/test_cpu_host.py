@@ -179,11 +179,25 @@ import numpy as np, torch, torch.distributed as dist
 from xai_engine import dist as xd, sweep
 rank, world, device = xd.init_from_env("gloo")
 assert world == 2 and device.type == "cpu"
-# (1) image sharding + the 11-element all-reduce
+# (1) image sharding + the 12-element all-reduce (10 sums, images, seconds in attribution)
 owned = sweep.shard_indices(7, rank, world)
 local = {k: float(sum((i + 1) * (j + 1) for i in owned)) for j, k in enumerate(sweep.KEYS)}
 total, used = sweep.reduce_counters(local, len(owned))
 assert used == 7
+_, _, secs = sweep.reduce_counters(local, len(owned), attr_seconds=1.5 + rank)
+assert secs == 4.0
+# (1b) the reference's order-dependent Counter fold over sharded images: ONE all-reduce of the zero-padded rows, replay in file order
+g = np.load(os.path.join(sys.argv[2], "tests", "golden", "sweep_counter.npz"))
+n_img = int(g["images_used"])
+calls = []
+real_ar = dist.all_reduce
+dist.all_reduce = lambda *a, **k: (calls.append(1), real_ar(*a, **k))[1]
+rows, flags, secs = sweep.gather_rows({i: g[f"counter_{i}"] for i in sweep.shard_indices(n_img, rank, world)}, n_img, attr_seconds=0.25)
+dist.all_reduce = real_ar
+assert len(calls) == 1 and flags.all() and secs == 0.5
+c = sweep.replay_reference_counter(rows[flags])
+assert list(c) == g["csv_keys"].tolist()
+assert [str(c[k] / n_img) for k in c] == g["csv_values"].tolist()
 for j, k in enumerate(sweep.KEYS):
     assert total[k] == sum((i + 1) * (j + 1) for i in range(7)), (k, total[k])
 # (2) RISE mask ranges tile [0, N) and every rank adopts rank 0's draw
@@ -229,6 +243,166 @@ def test_two_rank_gloo_sharding_and_reduction(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+EIGHT = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import numpy as np, torch, torch.distributed as dist
+from xai_engine import dist as xd, sweep, harness
+rank, world, device = xd.init_from_env("gloo")
+assert world == 8 and device.type == "cpu"
+# (1) BASELINE config 5 at 8 ranks: 1000 images round-robin, every image owned once, the 12-element all-reduce
+owned = sweep.shard_indices(1000, rank, world)
+assert len(owned) == 125 and owned[0] == rank and owned[-1] == 992 + rank
+total, used, secs = sweep.reduce_counters({k: float(len(owned)) for k in sweep.KEYS}, len(owned), attr_seconds=0.5)
+assert used == 1000 and secs == 4.0 and all(v == 1000.0 for v in total.values())
+# (2) the reference's Counter fold with FEWER images than ranks (ranks 5..7 own nothing) and with many (1000 rows = 88 KB)
+g = np.load(os.path.join(sys.argv[2], "tests", "golden", "sweep_counter.npz"))
+n_img = int(g["images_used"])
+rows, flags, _ = sweep.gather_rows({i: g[f"counter_{i}"] for i in sweep.shard_indices(n_img, rank, world)}, n_img)
+c = sweep.replay_reference_counter(rows[flags])
+assert list(c) == g["csv_keys"].tolist() and [str(c[k] / n_img) for k in c] == g["csv_values"].tolist()
+rng = np.random.default_rng(0)
+big = rng.standard_normal((1000, 10))
+rows, flags, _ = sweep.gather_rows({i: big[i] for i in owned}, 1000)
+assert flags.all() and np.array_equal(rows, big)
+want = sweep.replay_reference_counter(big)
+got = sweep.replay_reference_counter(rows)
+assert list(got) == list(want) and all(got[k] == want[k] for k in want)
+# (3) BASELINE config 3 at 8 ranks: 8000 masks in 8 contiguous ranges of 1000, rank 0's draw broadcast as ONE 576 016-byte message
+lo, hi = xd.mask_range(8000, rank, world)
+assert (lo, hi) == (1000 * rank, 1000 * (rank + 1))
+assert [xd.mask_range(8003, r, 8)[1] - xd.mask_range(8003, r, 8)[0] for r in range(8)] == [1001] * 3 + [1000] * 5
+r = np.random.RandomState(7 + rank)
+masks = ((r.rand(8000, 8, 8) < 0.5).astype(np.uint8), r.randint(0, 28, (8000, 2)).astype(np.int32), np.array([28, 28]))
+gd, sh, cell = xd.broadcast_masks(masks, device)
+r0 = np.random.RandomState(7)
+assert np.array_equal(gd, (r0.rand(8000, 8, 8) < 0.5).astype(np.uint8)) and np.array_equal(sh, r0.randint(0, 28, (8000, 2)).astype(np.int32))
+part = torch.full((224, 224), float(rank), dtype=torch.float64)
+assert float(xd.all_reduce_sum(part)[3, 3]) == 28.0
+# (4) the selection pre-pass at 8 ranks == 1 rank: chunk table, all-reduce, quota replay (the per-file verdict -- three classifier
+#     passes on the GPU in the product -- is replaced by a function of the file name; everything else is the product's code)
+import zlib
+def fake_verdict(model, blur, dev, path, img_hw, mean, std):
+    h = zlib.crc32(os.path.basename(path).encode())
+    return (h % 11 != 0), (h % 5 != 0), h % 7
+harness._verdict = fake_verdict
+harness.hip_device = lambda d: torch.device("cpu")
+harness.GaussianBlur = lambda *a, **k: None
+names = [f"ILSVRC2012_val_{i:08d}.JPEG" for i in range(1, 701)]
+td = {"models": [None], "imagenet_dataset": "/nonexistent", "img_hw": 224, "image_count": 100, "device": "cpu", "num_classes": 7}
+bitmap = np.ones(50000, dtype=np.int64); bitmap[::13] = 0
+for chunk in (32, 3):
+    mine = harness.select_images(td, bitmap, names=names, rank=rank, world=world, chunk_per_rank=chunk, lazy=True)
+    alone = harness.select_images(td, bitmap, names=names, rank=0, world=1, lazy=True)
+    assert mine[0] == alone[0] and mine[2] == alone[2] and len(mine[0]) == 100
+# a file that cannot be judged: every rank raises (none is left in the collective), with the file's name, unless it lies past the stop
+def bad_verdict(model, blur, dev, path, *a):
+    if path.endswith("00000050.JPEG") or path.endswith("00000699.JPEG"):
+        raise OSError("truncated file")
+    return fake_verdict(model, blur, dev, path, *a)
+harness._verdict = bad_verdict
+try:
+    harness.select_images(td, bitmap, names=names, rank=rank, world=world, chunk_per_rank=4, lazy=True)
+    raise SystemExit("no error raised")
+except RuntimeError as e:
+    assert "00000050.JPEG" in str(e)
+ok = harness.select_images(td, bitmap, names=names[60:], rank=rank, world=world, chunk_per_rank=4, lazy=True)     # ...699 is never reached
+assert len(ok[0]) == 100
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_eight_rank_gloo_rehearsal(tmp_path):
+    """World size 8 -- the node the driver's scaling run uses -- rehearsed on the CPU over gloo: image ownership and the reduce of
+    config 5, the reference-Counter gather with fewer images than ranks, the 8 x 1000 mask ranges and the packed 576 KB mask
+    broadcast of config 3, and the sharded selection pre-pass (chunk table, quota replay, error rows) == the 1-rank list."""
+    script = tmp_path / "worker8.py"
+    script.write_text(EIGHT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="8", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), PKG, ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(8)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert f"rank {r} ok" in o
+
+
+def test_special_version_fit_satisfies_the_KKT_conditions_of_the_reference_QP():
+    """MASMetric.single_run(special_version=True) (reference MASTestFunctions.py:311-350) smooths the normalised response with a
+    convex ('del') / concave ('ins') least-squares fit that the reference gets from cvxopt.  cvxopt is not importable here, so parity
+    with ITS output is unpinned; what is pinned is optimality: the product's curve satisfies the KKT conditions of the QP the reference
+    assembles (oracle.perturb.special_version_problem restates :313-345) to 1e-9 -- the problem is strictly convex, so that IS its
+    unique solution -- on the reference-made normalised curves of the golden fixtures and on random monotone curves; and it
+    agrees with a general-purpose solver (SLSQP) run on the same matrices."""
+    from xai_engine import curves
+    from oracle import perturb as op
+    cases = []
+    for fx in ("perturb_small.npz", "perturb_224.npz", "perturb_patch.npz"):
+        g = load_golden(fx)
+        cases += [(f"{fx}/{m}", g[f"MAS_{m}_ret4"], m) for m in ("del", "ins", "morf", "lerf")]
+    rng = np.random.default_rng(0)
+    for n in (3, 4, 5, 17, 100, 225):
+        fall = np.minimum.accumulate(np.clip(np.sort(rng.random(n))[::-1] + 0.15 * rng.standard_normal(n), 0, 1))
+        cases += [(f"random{n}/del", fall, "del"), (f"random{n}/ins", fall[::-1].copy(), "ins")]
+    cases.append(("already_convex", np.linspace(1, 0, 50) ** 2, "del"))
+    cases.append(("step", np.r_[np.ones(20), np.zeros(30)], "del"))
+    cases.append(("flat", np.full(9, 0.5), "ins"))
+    for name, y, mode in cases:
+        x = curves.shape_constrained_fit(y, mode)
+        assert x[0] == y[0] and x[-1] == y[-1], name
+        assert op.kkt_residual(x, y, mode) <= 1e-9, (name, op.kkt_residual(x, y, mode))
+        if mode in ("morf", "lerf") or name in ("already_convex", "flat"):
+            np.testing.assert_array_equal(x, y)                       # nothing binds: the reference's QP returns the curve itself
+        if mode == "del" and len(y) > 2:
+            assert (np.diff(x, 2) >= -1e-10).all(), name
+        if mode == "ins" and len(y) > 2:
+            assert (np.diff(x, 2) <= 1e-10).all(), name
+    g = load_golden("perturb_small.npz")                                # 33 points: SLSQP on the reference's matrices, seconds
+    for mode in ("del", "ins"):
+        y = g[f"MAS_{mode}_ret4"]
+        assert np.abs(curves.shape_constrained_fit(y, mode) - op.special_version_qp(y, mode)).max() <= 1e-8
+    nan = np.array([np.nan, 0.5, np.nan])
+    assert np.isnan(curves.shape_constrained_fit(nan, "del")).sum() == 2   # left to the reference's NaN guard downstream
+
+
+def test_reference_counter_fold_and_csv_reproduce_the_reference_rows(tmp_path):
+    """tests/golden/sweep_counter.npz: five images folded by the reference's `pert_result_counter += ...` and written by its CSV
+    loop (evaluatePerturbation.py:594-596,612-615): MONO_pos / MONO_neg / AIC_ins are dropped after the second image, MONO_* come
+    back after the third, AIC_ins after the fourth -- at the END of the row order, without their history."""
+    from xai_engine import sweep
+    g = load_golden("sweep_counter.npz")
+    n = int(g["images_used"])
+    for upto in range(n):
+        c = sweep.replay_reference_counter([g[f"counter_{i}"] for i in range(upto + 1)])
+        assert list(c) == g[f"keys_after_{upto}"].tolist()
+        assert [c[k] for k in c] == g[f"values_after_{upto}"].tolist()                   # bit-identical running sums
+    assert "MONO_pos" not in g["keys_after_1"].tolist() and g["keys_after_4"].tolist()[-1] == "AIC_ins"
+    c = sweep.replay_reference_counter([g[f"counter_{i}"] for i in range(n)])
+    path = tmp_path / "r" / "ig_5_images.csv"
+    sweep.write_csv(str(path), c, n, 2.5, 10.0, reference_counter=True)
+    rows = [r.split(",") for r in open(path).read().strip().splitlines()]
+    assert [r[0] for r in rows[:-2]] == g["csv_keys"].tolist() and [r[1] for r in rows[:-2]] == g["csv_values"].tolist()
+    assert rows[-2] == ["Attr Avg Runtime", "0.5"] and rows[-1] == ["Total Runtime", "10.0"]
+    # the default fold is a plain sum over the same per-image numbers and always writes ten rows: a different file on the same inputs
+    plain = {k: float(sum(g[f"counter_{i}"][j] for i in range(n))) for j, k in enumerate(sweep.KEYS)}
+    sweep.write_csv(str(path), plain, n, 2.5, 10.0)
+    rows = [r.split(",") for r in open(path).read().strip().splitlines()]
+    assert [r[0] for r in rows[:-2]] == list(sweep.KEYS)
+    assert float(rows[8][1]) < 0 < float(dict(g["csv_keys"].tolist() and zip(g["csv_keys"].tolist(), g["csv_values"].tolist()))["MONO_pos"])
+    assert sweep.replay_reference_counter([]) == {}
+    # a NaN Spearman (constant response) is dropped by `+=` exactly like a non-positive sum
+    c = sweep.replay_reference_counter([[1.0] * 10, [1.0] * 8 + [float("nan"), 1.0]])
+    assert "MONO_pos" not in c and c["MONO_neg"] == 2.0
 
 
 def test_harness_image_loading_and_name_parsing(tmp_path):

@@ -196,6 +196,23 @@ def test_sweep_counter():
     assert np.abs(total - g["counter_sum"]).max() <= 5e-5
 
 
+def test_sweep_counter_reference_fold():
+    """sweep_counter.npz: the oracle's ten numbers per image against the reference's, and the oracle's restatement of the
+    reference's Counter `+=` fold / CSV rows (evaluatePerturbation.py:594-596,612-615) against the reference-made rows."""
+    g = load_golden("sweep_counter.npz")
+    fn = logits_fn_of(tiny_from(g))
+    kern = op.gkern(31, 31)
+    blur = lambda im: op.blur_dense(im, kern)     # noqa: E731
+    n = int(g["images_used"])
+    for i in range(n):
+        c = op.run_perturbation(fn, g["x"][i:i + 1], g["saliency"][i], 32, blur, 50)
+        assert np.abs(np.array([c[k] for k in op.SWEEP_KEYS]) - g[f"counter_{i}"]).max() <= 2e-5
+    keys, values = op.reference_fold([g[f"counter_{i}"] for i in range(n)])
+    assert keys == g["csv_keys"].tolist()
+    assert [str(v / n) for v in values] == g["csv_values"].tolist()
+    assert keys[-1] == "AIC_ins" and keys.index("MONO_pos") == 7                        # dropped and re-entered at the end
+
+
 # ------------------------------------------------------------------ unpinned pieces: internal consistency
 def test_bilinear_matches_torch_interpolate():
     """The call the reference reaches through torchvision Resize(antialias=True)."""
