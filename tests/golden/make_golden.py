@@ -30,6 +30,8 @@ What is pinned (reference file:line in brackets):
   smoothgrad.npz              seeded smoothGrad("IG", ..., vis=True): mean, total_gradients, noisy_imgs [saliencyMethods.py:184-205]
   sweep_small.npz             the 10-key Counter of run_perturbation, driven exactly like
                               XAI_Survey/evaluations/evaluatePerturbation.py:448-497
+  zoo_state_dicts.npz         state-dict key names and tensor shapes of the classifiers the reference's harness instantiates
+                              [util/modified_models/resnet.py:430-560 (torchvision layout), VIT_LRP/ViT_ig.py:256-273]
   sweep_counter.npz           five images folded with the reference's `pert_result_counter += ...` (:594-596) and written with its CSV
                               loop (:612-615): keys whose running sum is <= 0 are dropped and re-enter at the end
 The only stubs are inert placeholder modules: `cvxopt` (used by the reference only under
@@ -397,6 +399,37 @@ def counter_fixture():
         print("  after image", n, list(out[f"keys_after_{n}"]))
 
 
+def zoo_fixture():
+    """Key names and shapes of the state dicts a `--weights` checkpoint for the reference's classifiers holds: the reference's vendored
+    torchvision ResNet definitions (util/modified_models/resnet.py; its `_presets` import needs two inert torchvision.transforms
+    names) and its hooked ViT-B/16 (VIT_LRP/ViT_ig.py; the /32 variant lives in ViT_new_timm.py, which needs timm: absent).
+    Random initialisation only -- `weights=None` / `pretrained=False`; nothing is fetched."""
+    import enum
+    tv = types.ModuleType("torchvision"); tvt = types.ModuleType("torchvision.transforms")
+
+    class InterpolationMode(enum.Enum):
+        NEAREST = "nearest"; BILINEAR = "bilinear"; BICUBIC = "bicubic"
+    tvt.InterpolationMode = InterpolationMode
+    tvt.functional = types.SimpleNamespace()
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv); sys.modules.setdefault("torchvision.transforms", tvt)
+    from util.modified_models import resnet as ref_resnet
+    from util.attribution_methods.VIT_LRP.ViT_ig import vit_base_patch16_224
+    out = {}
+    makers = {"resnet50": lambda: ref_resnet.resnet50(weights=None), "resnet101": lambda: ref_resnet.resnet101(weights=None),
+              "resnet152": lambda: ref_resnet.resnet152(weights=None), "resnext101_64x4d": lambda: ref_resnet.resnext101_64x4d(weights=None),
+              "vit_base_patch16_224": lambda: vit_base_patch16_224(pretrained=False)}
+    for name, make in makers.items():
+        sd = make().state_dict()
+        out[name + "_keys"] = np.array(list(sd))
+        shapes = np.zeros((len(sd), 4), dtype=np.int64)
+        for i, v in enumerate(sd.values()):
+            shapes[i, :v.dim()] = list(v.shape)
+        out[name + "_shapes"] = shapes
+        print(name, len(sd), "entries,", sum(int(v.numel()) for v in sd.values()), "elements")
+    np.savez_compressed(os.path.join(HERE, "zoo_state_dicts.npz"), **out)
+
+
 def vit_fixture():
     """Mini hooked ViT of the reference (ViT_ig.py:161-253; 32x32 image, patch 8, dim 32, depth 2,
     4 heads, 10 classes): pixel-space IG through saliencyMethods.IG and attention-space IG through
@@ -587,6 +620,7 @@ if __name__ == "__main__":
     perturb_fixture("perturb_ties.npz", 32, 32, 330, 10, keep_images=False, ties=True)   # tied map: the reference's own (unstable) order recorded
     sweep_fixture()
     counter_fixture()
+    zoo_fixture()
     vit_fixture()
     cam_fixture()
     vitcx_fixture()

@@ -511,6 +511,21 @@ def test_tolerances_are_tied_to_measured_errors():
     assert above == ["IG/ig_224.npz/ig_tensor_baseline/under_ill_conditioned_gates", "getSlopes/ig_small"], above
 
 
+def test_model_zoo_state_dicts_have_the_reference_definitions_keys_and_shapes():
+    """tests/golden/zoo_state_dicts.npz: every state-dict key and tensor shape of the reference's own classifier definitions (its
+    vendored torchvision ResNets, util/modified_models/resnet.py, and its hooked ViT-B/16, VIT_LRP/ViT_ig.py).  The build's zoo must
+    match entry for entry, in order, so that a `--weights` checkpoint made for the reference loads with strict=True.
+    What this does NOT pin: the RESULTS of R101 / R152 / RNXT / VIT32 runs -- no reference-made fixture covers them (construct-and-run
+    only, tests/test_gpu_e2e.py::test_fuse_bn_relu_on_resnext_and_the_deeper_resnets, test_cli...): parity unpinned, DESIGN.md section 2."""
+    from xai_engine import zoo
+    g = load_golden("zoo_state_dicts.npz")
+    for name in ("resnet50", "resnet101", "resnet152", "resnext101_64x4d", "vit_base_patch16_224"):
+        sd = getattr(zoo, name)().state_dict()
+        assert list(sd) == g[name + "_keys"].tolist(), name
+        for (k, v), shape in zip(sd.items(), g[name + "_shapes"]):
+            assert tuple(v.shape) == tuple(int(d) for d in shape[:v.dim()]) and not shape[v.dim():].any(), (name, k, tuple(v.shape), shape)
+
+
 def test_model_zoo_matches_the_architectures_the_reference_harness_names():
     """evaluatePerturbation.py:627-659 instantiates torchvision's resnet101 / resnext101_64x4d and timm-layout ViT-B/16, /32; the
     build's definitions must take their state dicts as they are: same parameter counts (torchvision / timm's published numbers),
