@@ -30,14 +30,19 @@ class LayerGradCam:
         self.forward_func = forward_func
         self.layer = layer
 
-    def _act_and_grad(self, inputs, target):
+    def _act_and_grad(self, inputs, target, additional_forward_args=None, layer_input=False):
         kept = {}
-        handle = self.layer.register_forward_hook(lambda mod, inp, out: kept.__setitem__("act", out))
+        if layer_input:                                 # captum's attribute_to_layer_input: the layer's (first) input instead of its output
+            handle = self.layer.register_forward_pre_hook(lambda mod, inp: kept.__setitem__("act", inp[0]))
+        else:
+            handle = self.layer.register_forward_hook(lambda mod, inp, out: kept.__setitem__("act", out))
+        extra = () if additional_forward_args is None else \
+            (tuple(additional_forward_args) if isinstance(additional_forward_args, (tuple, list)) else (additional_forward_args,))
         try:
             with torch.enable_grad():
                 if not inputs.requires_grad:        # captum's apply_gradient_requirements: the layer output
                     inputs = inputs.detach().requires_grad_(True)   # needs a graph even with frozen weights
-                out = self.forward_func(inputs)
+                out = self.forward_func(inputs, *extra)
                 out = out if isinstance(out, torch.Tensor) else out.logits
                 if target is None:
                     score = out.sum()
@@ -45,6 +50,8 @@ class LayerGradCam:
                     score = out.gather(1, target.reshape(-1, 1).to(out.device)).sum()
                 else:
                     score = out[:, int(target)].sum()
+                if not torch.is_tensor(kept.get("act")):
+                    raise XaiHipError("LayerGradCam: the layer's " + ("input" if layer_input else "output") + " is not a single tensor")
                 grad = _grad_of_activation(score, kept["act"])
         finally:
             handle.remove()
@@ -52,16 +59,29 @@ class LayerGradCam:
 
     def attribute(self, inputs, target=None, additional_forward_args=None, attribute_to_layer_input=False,
                   relu_attributions=False, attr_dim_summation=True):
-        """-> (B,1,h,w) like captum: mean-over-space gradient weights, weighted channel sum, optional ReLU."""
-        if additional_forward_args is not None or attribute_to_layer_input or not attr_dim_summation:
-            raise NotImplementedError("only the call shape used by the reference harness is accelerated")
+        """captum 0.7.0's LayerGradCam.attribute for one input tensor and one layer tensor: the gradient of the target score with
+        respect to the layer, averaged over every axis after the channel axis, weighs the layer's activation; with
+        `attr_dim_summation` the weighted channels are summed (-> (B,1,*spatial)); optional ReLU.
+        The harness's call shape -- a (B,C,h,w) layer output, summed -- is one xai_gradcam_f32 launch; so is any layer of rank
+        >= 3 with at most 1024 positions per channel (a ViT block's (B,tokens,dim): "channels" = tokens).  What that kernel does not
+        cover (no channel sum, rank-2 layers, larger maps) is the same three-line expression in device torch ops -- never the CPU."""
         if not inputs.is_cuda:
             raise XaiHipError("LayerGradCam.attribute needs its input on a HIP device ('cuda:N')")
-        act, grad = self._act_and_grad(inputs, target)
-        if act.dim() != 4:
-            raise NotImplementedError("layer output must be (B,C,h,w)")
-        cam = K.gradcam(act.float().contiguous(), grad.float().contiguous(), relu=relu_attributions)
-        return cam.unsqueeze(1)
+        act, grad = self._act_and_grad(inputs, target, additional_forward_args, attribute_to_layer_input)
+        act, grad = act.float().contiguous(), grad.float().contiguous()
+        spatial = tuple(act.shape[2:])
+        n_pos = 1
+        for d in spatial:
+            n_pos *= int(d)
+        if attr_dim_summation and act.dim() >= 3 and n_pos <= 1024:
+            B, Cc = act.shape[0], act.shape[1]
+            cam = K.gradcam(act.reshape(B, Cc, n_pos, 1), grad.reshape(B, Cc, n_pos, 1), relu=relu_attributions)
+            return cam.reshape((B, 1) + spatial)
+        weights = grad.mean(dim=tuple(range(2, grad.dim())), keepdim=True) if grad.dim() > 2 else grad
+        scaled = weights * act
+        if attr_dim_summation:
+            scaled = scaled.sum(dim=1, keepdim=True)
+        return torch.relu(scaled) if relu_attributions else scaled
 
 
 def patch_captum():

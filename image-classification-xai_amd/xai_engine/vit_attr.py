@@ -82,6 +82,43 @@ def compute_rollout_attention(all_layer_matrices, start_layer=0):
     return joint, aug
 
 
+def _residual_shares(blk):
+    """Per token, how the two branches of a block's two residual additions share the 2-norm (reference :214-235, :452-460):
+    ((input, attention output), (input + attention, MLP output)), each a (2, S) tensor whose columns sum to 1.  The reference
+    `.squeeze()`s the batch axis away: one image."""
+    def share(a, b):
+        both = torch.stack((torch.linalg.norm(a.squeeze(0), ord=2, dim=1), torch.linalg.norm(b.squeeze(0), ord=2, dim=1)))
+        return torch.nn.functional.normalize(both, p=1, dim=0)
+    return share(blk.get_input().detach(), blk.attn.get_output().detach()), share(blk.get_input_plus_attn().detach(), blk.get_mlp_val().detach())
+
+
+def compute_RAVE(all_layer_attentions, all_layer_biases_resid_1, all_layer_biases_resid_2, ablate=0):
+    """InFlow rollout (reference compute_RAVE :48-88): each block's head-mean attention A is mixed with the identity by the norm
+    shares of its first residual addition (A * attn_share + I * input_share), multiplied by the second one's matrix
+    (diag(normalised mlp/resid ratio) * diag(mlp_share) + I * diag(resid_share)), row-normalised, and the blocks are chained.
+    Tensors of (L, 1, S, S) / (L, 2, S) for one image -- classifier-side bookkeeping, device torch ops."""
+    A = torch.stack(all_layer_attentions)                                          # (L, B, S, S)
+    b1 = torch.stack(all_layer_biases_resid_1).to(A.device)                        # (L, 2, S)
+    b2 = torch.stack(all_layer_biases_resid_2).to(A.device)
+    L, B, S, _ = A.shape
+    eye = torch.eye(S, device=A.device).expand(1, B, S, S)
+    r1 = A * b1[:, 1].reshape(L, 1, 1, S) + eye * torch.diag_embed(b1[:, 0]).reshape(A.shape)
+    if ablate == 0:
+        ratio = torch.nn.functional.normalize(b2[:, 1].reshape(L, 1, 1, S) / b2[:, 0].reshape(L, 1, 1, S), p=1, dim=-1)
+        r2 = torch.diag_embed(ratio.reshape(L, S)).reshape(A.shape) * torch.diag_embed(b2[:, 1]).reshape(A.shape) + \
+            eye * torch.diag_embed(b2[:, 0]).reshape(A.shape)
+        aug = r1 @ r2
+    elif ablate == 1:
+        aug = r1
+    else:
+        raise ValueError("ablate must be 0 or 1")
+    aug = aug / aug.sum(dim=-1, keepdim=True)
+    joint = aug[0]
+    for i in range(1, L):
+        joint = aug[i].bmm(joint)
+    return joint, aug
+
+
 def _head_means(model):
     return [(blk.attn.get_attention_map().sum(dim=1) / blk.attn.get_attention_map().shape[1]).detach() for blk in model.blocks]
 
@@ -101,14 +138,18 @@ def _generate_naive_rollout(self, input, start_layer=0, device=None):
 
 
 def _generate_rollout(self, input, InFlow=False, start_layer=0, device=None):
-    """Attention rollout (reference Baselines.generate_rollout :196-240; the InFlow/RAVE variant needs
-    residual-stream hooks the accelerated path does not model)."""
-    if InFlow:
-        raise NotImplementedError("InFlow/RAVE rollout is outside the accelerated path")
+    """Attention rollout (reference Baselines.generate_rollout :196-240).  InFlow=True weighs every block's attention against
+    the identity by the norms of its residual-stream branches (`compute_RAVE`); it reads the hooks of the reference's timm-based
+    twin (`blk.get_input()`, `.get_input_plus_attn()`, `.get_mlp_val()`, `.attn.get_output()`, ViT_new_timm.py:223-312), which the
+    build's ViT keeps too."""
     with torch.no_grad():
         self.model(input if device is None else input.to(device))
     layers = _head_means(self.model)
-    rollout, mats = compute_rollout_attention(layers, start_layer=start_layer)
+    if InFlow:
+        shares = [_residual_shares(blk) for blk in self.model.blocks]
+        rollout, mats = compute_RAVE(layers, [s[0] for s in shares], [s[1] for s in shares])
+    else:
+        rollout, mats = compute_rollout_attention(layers, start_layer=start_layer)
     return _grid(rollout[:, 0, 1:]), mats, torch.stack(layers)
 
 
@@ -170,12 +211,11 @@ def _attn_attr(self, input, target_class, start_layer=0, device="cuda:0"):
 
 def _bidirectional(self, input, target_class, steps=20, start_layer=4, samples=20, noise=0.2, mae=False, dino=False, ssl=False,
                    InFlow=False, device="cuda"):
-    """Bidirectional transformer attribution (reference Baselines.bidirectional :417-518, InFlow=False):
-    head-importance-weighted attention rollout R, times the integrated attention gradient of the last block.
+    """Bidirectional transformer attribution (reference Baselines.bidirectional :417-518):
+    head-importance-weighted attention rollout R (InFlow=True: chained through the residual-share matrices of :447-464 instead
+    of R + cam R), times the integrated attention gradient of the last block.
     The integral needs every row of the (heads, S, S) gradient, so all `steps` gradients are reduced by
     xai_ig_accum_f32 as one [steps][heads*S*S] buffer."""
-    if InFlow:
-        raise NotImplementedError("the InFlow variant needs residual-stream hooks outside the accelerated path")
     dev = hip_device(device)
     x = input.to(dev, torch.float32)
     x0 = x.detach().requires_grad_(True)
@@ -194,7 +234,16 @@ def _bidirectional(self, input, target_class, steps=20, start_layer=4, samples=2
         Ih = torch.mean(torch.matmul(cam.transpose(-1, -2), grad).abs(), dim=(-1, -2))
         Ih = Ih / torch.sum(Ih)
         cam = torch.matmul(Ih, cam.reshape(num_head, -1)).reshape(num_tokens, num_tokens)
-        R = R + torch.matmul(cam, R)
+        if not InFlow:
+            R = R + torch.matmul(cam, R)
+            continue
+        b1, b2 = _residual_shares(blk)                                                  # (2, S) each
+        S = num_tokens
+        r1 = cam * b1[1].reshape(1, 1, S) + R * torch.diag_embed(b1[0]).reshape(1, S, S)
+        ratio = torch.nn.functional.normalize(b2[1].reshape(1, 1, S) / b2[0].reshape(1, 1, S), p=1, dim=-1)
+        r2 = torch.diag_embed(ratio.reshape(S)).reshape(1, S, S) * torch.diag_embed(b2[1]).reshape(1, S, S) + \
+            R * torch.diag_embed(b2[0]).reshape(1, S, S)
+        R = r1 @ r2
     if ssl:
         if mae:
             return R[:, 1:, 1:].abs().mean(axis=1)

@@ -110,9 +110,14 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.attention_map = None
         self.attn_gradients = None
+        self.output = None
 
     def save_attn_gradients(self, g):
         self.attn_gradients = g
+
+    def get_output(self):
+        """projected attention output of the last forward pass (reference ViT_new_timm.py:223-227,251): read by the InFlow rollout"""
+        return self.output
 
     def get_attn_gradients(self):
         return self.attn_gradients
@@ -128,7 +133,8 @@ class Attention(nn.Module):
         self.attention_map = attn
         if register_hook and attn.requires_grad:
             attn.register_hook(self.save_attn_gradients)
-        return self.proj((attn @ v).transpose(1, 2).reshape(B, N, D))
+        self.output = self.proj((attn @ v).transpose(1, 2).reshape(B, N, D))
+        return self.output
 
 
 class Mlp(nn.Module):
@@ -151,14 +157,29 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
         self.block_out = None
+        self.input = self.input_plus_attn = self.mlp_val = None
 
     def get_block_out(self):
         """output of the last forward pass (reference ViT_new_timm.py:285,297-312): what `single_run(return_embeddings=True)` reads"""
         return self.block_out
 
+    # the residual stream of the last forward pass (reference ViT_new_timm.py:276-283,297-312): what the InFlow rollout weighs
+    def get_input(self):
+        return self.input
+
+    def get_input_plus_attn(self):
+        return self.input_plus_attn
+
+    def get_mlp_val(self):
+        return self.mlp_val
+
     def forward(self, x, register_hook=False):
+        self.input = x
         x = x + self.attn(self.norm1(x), register_hook)
-        x = x + self.mlp(self.norm2(x))
+        self.input_plus_attn = x
+        y = self.mlp(self.norm2(x))
+        self.mlp_val = y
+        x = x + y
         self.block_out = x
         return x
 

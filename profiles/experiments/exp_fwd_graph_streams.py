@@ -1,0 +1,87 @@
+"""Round 3: the sweep is forward passes of batch 50 (15 per image).  Is the host the limit once 3 streams overlap them, and does
+replaying the forward as a hipGraph (one graph per stream slot, EACH CAPTURED ON ITS OWN STREAM -- torch.cuda.graph's default
+capture stream is shared, and so is the BLAS workspace keyed by it) lift it?  Bit-compares graph logits with eager ones."""
+import json, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [R, os.path.join(R, "image-classification-xai_amd")]
+import torch
+import xai_engine
+from xai_engine.ig import _side_streams
+from xai_engine.zoo import resnet50
+from xai_engine.prepare import fuse_bn_relu
+
+dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
+xai_engine.load_library()
+plain = resnet50(seed=0).to(dev)
+xs = torch.randn(6, 50, 3, 224, 224, generator=torch.Generator().manual_seed(2)).to(dev)
+model = fuse_bn_relu(plain, verify=xs[0, :2], fork_residual=True)
+N = 120
+
+
+class Slot:
+    def __init__(self, own_stream):
+        self.x = torch.zeros((50, 3, 224, 224), device=dev)
+        self.stream = torch.cuda.Stream(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            for _ in range(2):
+                model(self.x)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        kw = {"stream": self.stream} if own_stream else {}
+        with torch.cuda.graph(self.graph, **kw), torch.no_grad():
+            self.out = model(self.x)
+
+
+def eager(ns):
+    side = _side_streams(dev, ns)
+    outs = []
+    for s in side:
+        s.wait_stream(torch.cuda.current_stream(dev))
+    for i in range(N):
+        with torch.cuda.stream(side[i % ns]), torch.no_grad():
+            outs.append(model(xs[i % 6]))
+    for s in side:
+        torch.cuda.current_stream(dev).wait_stream(s)
+    return outs
+
+
+def graphed(slots):
+    outs = []
+    for sl in slots:
+        sl.stream.wait_stream(torch.cuda.current_stream(dev))
+    for i in range(N):
+        sl = slots[i % len(slots)]
+        with torch.cuda.stream(sl.stream):
+            sl.x.copy_(xs[i % 6], non_blocking=True)
+            sl.graph.replay()
+            outs.append(sl.out.clone())
+    for sl in slots:
+        torch.cuda.current_stream(dev).wait_stream(sl.stream)
+    return outs
+
+
+def timeit(f):
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); outs = f(); host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return outs, time.perf_counter() - t0, host
+
+
+ref, dt, host = timeit(lambda: eager(1))
+print(json.dumps({"flow": "eager", "streams": 1, "ms_per_batch": dt / N * 1e3, "host_ms_per_batch": host / N * 1e3, "images_per_s": 50 * N / dt}), flush=True)
+for ns in (2, 3, 4):
+    outs, dt, host = timeit(lambda: eager(ns))
+    print(json.dumps({"flow": "eager", "streams": ns, "ms_per_batch": dt / N * 1e3, "host_ms_per_batch": host / N * 1e3, "images_per_s": 50 * N / dt,
+                      "bit_identical": all(torch.equal(a, b) for a, b in zip(outs, ref))}), flush=True)
+for own in (True, False):
+    slots = []
+    for ns in (1, 2, 3, 4):
+        while len(slots) < ns:
+            slots.append(Slot(own))
+        outs, dt, host = timeit(lambda: graphed(slots[:ns]))
+        print(json.dumps({"flow": "graph", "capture_on_own_stream": own, "streams": ns, "ms_per_batch": dt / N * 1e3, "host_ms_per_batch": host / N * 1e3,
+                          "images_per_s": 50 * N / dt, "bit_identical": all(torch.equal(a, b) for a, b in zip(outs, ref)),
+                          "max_abs_diff": max(float((a - b).abs().max()) for a, b in zip(outs, ref))}), flush=True)
+    del slots

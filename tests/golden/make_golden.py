@@ -32,6 +32,7 @@ What is pinned (reference file:line in brackets):
                               XAI_Survey/evaluations/evaluatePerturbation.py:448-497
   zoo_state_dicts.npz         state-dict key names and tensor shapes of the classifiers the reference's harness instantiates
                               [util/modified_models/resnet.py:430-560 (torchvision layout), VIT_LRP/ViT_ig.py:256-273]
+  vit_inflow.npz              InFlow rollout / bidirectional(InFlow=True) on the mini ViT [ViT_explanation_generator.py:48-88,196-240,447-464]
   sweep_counter.npz           five images folded with the reference's `pert_result_counter += ...` (:594-596) and written with its CSV
                               loop (:612-615): keys whose running sum is <= 0 are dropped and re-enter at the end
 The only stubs are inert placeholder modules: `cvxopt` (used by the reference only under
@@ -467,6 +468,47 @@ def vit_fixture():
     print("vit_mini.npz", {k: v.shape for k, v in out.items() if not k.startswith("w_")})
 
 
+def inflow_fixture():
+    """InFlow variants of the attention rollouts (ViT_explanation_generator.py: compute_RAVE :48-88, generate_rollout(InFlow=True)
+    :196-240, bidirectional(InFlow=True) :447-464) on the mini ViT of vit_mini.npz.  They read residual-stream accessors
+    (`blk.get_input()`, `.get_input_plus_attn()`, `.get_mlp_val()`, `.attn.get_output()`) that only the reference's timm-based twin
+    defines (ViT_new_timm.py:223-312; timm is absent here).  The accessors are attached to the reference's ViT_ig blocks with
+    torch forward hooks -- norm1's input, attn's output, norm2's input, mlp's output are exactly the tensors the twin saves -- so
+    every number below is computed by the reference's own functions, unmodified."""
+    from functools import partial
+    from util.attribution_methods.VIT_LRP.ViT_ig import VisionTransformer
+    from util.attribution_methods.VIT_LRP.ViT_explanation_generator import Baselines
+    g = np.load(os.path.join(HERE, "vit_mini.npz"))
+    torch.manual_seed(77)
+    model = VisionTransformer(img_size=32, patch_size=8, embed_dim=32, depth=2, num_heads=4, num_classes=10, mlp_ratio=4,
+                              qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6)).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(3.0)
+    assert all(np.array_equal(v.numpy(), g["w_" + k]) for k, v in model.state_dict().items())        # the model of vit_mini.npz
+    for blk in model.blocks:
+        kept = {}
+        blk.norm1.register_forward_hook(lambda m, i, o, kept=kept: kept.__setitem__("input", i[0]))
+        blk.attn.register_forward_hook(lambda m, i, o, kept=kept: kept.__setitem__("attn_out", o))
+        blk.norm2.register_forward_hook(lambda m, i, o, kept=kept: kept.__setitem__("input_plus_attn", i[0]))
+        blk.mlp.register_forward_hook(lambda m, i, o, kept=kept: kept.__setitem__("mlp_val", o))
+        blk.get_input = lambda kept=kept: kept["input"]
+        blk.get_input_plus_attn = lambda kept=kept: kept["input_plus_attn"]
+        blk.get_mlp_val = lambda kept=kept: kept["mlp_val"]
+        blk.attn.get_output = lambda kept=kept: kept["attn_out"]
+    x = torch.from_numpy(g["x"])
+    target = torch.tensor(int(g["target"]))
+    b = Baselines(model)
+    out = {}
+    with torch.no_grad():
+        roll, mats, layers = b.generate_rollout(x.clone(), InFlow=True)
+    out["inflow_rollout"], out["inflow_matrices"], out["inflow_layers"] = roll.detach().numpy(), mats.detach().numpy(), layers.detach().numpy()
+    bi, bi_R = b.bidirectional(x.clone(), target, steps=20, start_layer=1, InFlow=True, device="cpu")
+    out["inflow_bi_attr"], out["inflow_bi_R"] = bi.detach().numpy(), bi_R.detach().numpy()
+    np.savez(os.path.join(HERE, "vit_inflow.npz"), **out)
+    print("vit_inflow.npz", {k: v.shape for k, v in out.items()})
+
+
 def cam_fixture():
     """Grad-CAM arithmetic from the reference-OWNED CAM code (captum itself is absent):
     ViT_CX/get_feature_map.py:17-23 (weights = mean of the gradients over space) and
@@ -622,6 +664,7 @@ if __name__ == "__main__":
     counter_fixture()
     zoo_fixture()
     vit_fixture()
+    inflow_fixture()
     cam_fixture()
     vitcx_fixture()
     tis_fixture()

@@ -354,6 +354,68 @@ def test_model_utils_and_gradcam_call_shape():
     assert rel_inf(sal.cpu().numpy(), ogc.gradcam_saliency(act, grad, 64, 64)) <= 1e-5
 
 
+def test_gradcam_other_captum_call_shapes():
+    """LayerGradCam.attribute beyond the harness's call (VERDICT r2 missing 4): attr_dim_summation=False, attribute_to_layer_input,
+    additional_forward_args, a token-shaped (B,N,D) layer, a rank-2 layer -- each against captum 0.7.0's published expression
+    (mean of the layer gradient over the axes after the channel axis, times the activation, optional channel sum, optional ReLU)
+    written out in float64.  captum is not importable here: parity with captum itself stays unpinned."""
+    from helpers import vit_mini_from
+    from xai_engine.gradcam import LayerGradCam
+    from oracle import gradcam as ogc
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    xd = torch.from_numpy(g["x"]).to(DEV)
+    t = int(g["target"])
+
+    def captum_expr(act, grad, summed, relu):
+        a, gr = torch.as_tensor(act).double(), torch.as_tensor(grad).double()
+        w = gr.mean(dim=tuple(range(2, gr.dim())), keepdim=True) if gr.dim() > 2 else gr
+        out = w * a
+        out = out.sum(dim=1, keepdim=True) if summed else out
+        return (out.clamp(min=0) if relu else out).numpy()
+
+    act, grad = ogc.layer_act_and_grad(model, model.conv, xd, t)                       # (1,8,32,32) numpy
+    for summed in (True, False):
+        for relu in (True, False):
+            got = LayerGradCam(model, model.conv).attribute(xd, t, relu_attributions=relu, attr_dim_summation=summed)
+            want = captum_expr(act, grad, summed, relu)
+            assert got.shape == want.shape
+            check(f"gradcam_shapes/conv/summed={summed}/relu={relu}", got.cpu().numpy(), want, 1e-5, "captum 0.7.0's expression")
+    # the layer's INPUT instead of its output: for `act` (ReLU) that is the conv output again
+    got = LayerGradCam(model, model.act).attribute(xd, t, attribute_to_layer_input=True)
+    pre = {}
+    h = model.act.register_forward_pre_hook(lambda m, i: pre.__setitem__("a", i[0]))
+    xr = xd.clone().requires_grad_(True)
+    out = model(xr)
+    h.remove()
+    (gin,) = torch.autograd.grad(out[0, t], pre["a"])
+    check("gradcam_shapes/layer_input", got.cpu().numpy(), captum_expr(pre["a"].detach().cpu(), gin.cpu(), True, False), 1e-5, "captum 0.7.0's expression")
+    # rank-2 layer (after Flatten): no axes to average, the gradient itself weighs the activation
+    got = LayerGradCam(model, model.pool).attribute(xd, t)                             # (1,8,4,4): 16 positions
+    assert got.shape == (1, 1, 4, 4)
+    flat = torch.nn.Sequential(model.conv, model.act, model.pool, torch.nn.Flatten())
+    head = torch.nn.Sequential(flat, model.fc)
+    got2 = LayerGradCam(head, flat).attribute(xd, t)
+    a2 = flat(xd).detach().requires_grad_(True)
+    (g2,) = torch.autograd.grad(model.fc(a2)[0, t], a2)
+    assert got2.shape == (1, 1)
+    check("gradcam_shapes/rank2", got2.cpu().numpy(), captum_expr(a2.detach().cpu(), g2.cpu(), True, False), 1e-5, "captum 0.7.0's expression")
+    # token-shaped layer of the hooked ViT, through additional_forward_args (register_hook=False)
+    gv = load_golden("vit_mini.npz")
+    vit = vit_mini_from(gv, DEV)
+    xv = torch.from_numpy(gv["x"]).to(DEV)
+    blk = vit.blocks[-1]
+    got = LayerGradCam(vit, blk).attribute(xv, int(gv["target"]), additional_forward_args=(False,), relu_attributions=True)
+    assert got.shape == (1, 1, 32)                                                     # (B, 1, dim): tokens are the "channels"
+    kept = {}
+    hh = blk.register_forward_hook(lambda m, i, o: kept.__setitem__("a", o))
+    out = vit(xv.clone().requires_grad_(True), False)
+    hh.remove()
+    (gt,) = torch.autograd.grad(out[0, int(gv["target"])], kept["a"])
+    check("gradcam_shapes/vit_block_tokens", got.cpu().numpy(), captum_expr(kept["a"].detach().cpu(), gt.cpu(), True, True), 1e-5,
+          "captum 0.7.0's expression")
+
+
 # ------------------------------------------------------------------------------ harness counterpart (f1)
 def test_run_perturbation_and_fused_sweep_match_reference_counters():
     """The 10-key Counter of evaluatePerturbation.run_perturbation: eight single_runs (reference
@@ -495,6 +557,17 @@ def test_vit_pixel_ig_and_attention_ig(attr):
     check("vit_mini/bi_attr", bi.cpu().numpy(), g["bi_attr"], 1e-5)
     check("vit_mini/bi_R", bi_R.cpu().numpy(), g["bi_R"], 1e-5)
     check("vit_mini/bi_mae", b.bidirectional(x.clone(), t, steps=20, start_layer=1, mae=True, device=DEV).cpu().numpy(), g["bi_mae"], 1e-5)
+    # InFlow variants (compute_RAVE, ViT_explanation_generator.py:48-88,:214-238,:447-464): the reference's own functions ran on this
+    # model for vit_inflow.npz (tests/golden/make_golden.py: inflow_fixture)
+    gi = load_golden("vit_inflow.npz")
+    roll, mats, layers = b.generate_rollout(xd, InFlow=True)
+    check("vit_mini/inflow_rollout", roll.cpu().numpy(), gi["inflow_rollout"], 1e-5)
+    check("vit_mini/inflow_matrices", mats.cpu().numpy(), gi["inflow_matrices"], 1e-5)
+    check("vit_mini/inflow_layers", layers.cpu().numpy(), gi["inflow_layers"], 1e-5)
+    check("vit_mini/inflow_rollout", roll.cpu().numpy(), ovit.inflow_rollout(model, g["x"])[0], 1e-5, "oracle")
+    bi, bi_R = b.bidirectional(x.clone(), t, steps=20, start_layer=1, InFlow=True, device=DEV)
+    check("vit_mini/inflow_bi_attr", bi.cpu().numpy(), gi["inflow_bi_attr"], 1e-5)
+    check("vit_mini/inflow_bi_R", bi_R.cpu().numpy(), gi["inflow_bi_R"], 1e-5)
 
 
 def test_evaluate_perturbation_on_a_directory(tmp_path):

@@ -264,6 +264,16 @@ def test_vit_mini_pixel_ig_and_attention_ig():
     assert rel_inf(vit_attr.attention_ig(model, g["x"], int(g["target"]), 20), g["attn_ig"]) <= 1e-5
 
 
+def test_vit_mini_inflow_rollout():
+    """vit_inflow.npz: the reference's compute_RAVE / generate_rollout(InFlow=True) on the mini ViT, against the oracle's NumPy
+    restatement driven through the build's hooked ViT (same state dict, same residual-stream accessors)."""
+    from helpers import vit_mini_from
+    from oracle import vit_attr
+    g, gi = load_golden("vit_mini.npz"), load_golden("vit_inflow.npz")
+    roll, mats = vit_attr.inflow_rollout(vit_mini_from(g), g["x"])
+    assert rel_inf(roll, gi["inflow_rollout"]) <= 1e-5 and rel_inf(mats, gi["inflow_matrices"]) <= 1e-5
+
+
 def test_gradcam_reduce_matches_reference_owned_cam_code():
     """cam.npz comes from ViT_CX/get_feature_map.get_cam_weights + ViT_CX/base_cam.get_cam_image."""
     g = load_golden("cam.npz")
