@@ -404,9 +404,11 @@ def test_gradcam_other_captum_call_shapes():
     gv = load_golden("vit_mini.npz")
     vit = vit_mini_from(gv, DEV)
     xv = torch.from_numpy(gv["x"]).to(DEV)
-    blk = vit.blocks[-1]
+    # (tokens, hidden).  Not a block output: every reader of the residual stream is a LayerNorm, so the gradient of a block output
+    # sums to zero over dim -- Grad-CAM weights of pure rounding noise
+    blk = vit.blocks[0].mlp.act
     got = LayerGradCam(vit, blk).attribute(xv, int(gv["target"]), additional_forward_args=(False,), relu_attributions=True)
-    assert got.shape == (1, 1, 32)                                                     # (B, 1, dim): tokens are the "channels"
+    assert got.shape == (1, 1, 128)                                                    # (B, 1, hidden): tokens are the "channels"
     kept = {}
     hh = blk.register_forward_hook(lambda m, i, o: kept.__setitem__("a", o))
     out = vit(xv.clone().requires_grad_(True), False)
