@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--rise-masks", type=int, default=8000)
     ap.add_argument("--rise-batch", type=int, default=250)
     ap.add_argument("--sweep-images", type=int, default=4, help="images per rank")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams for RISE's mask batches and the sweep's images (bit-identical to 1)")
     ap.add_argument("--check", type=int, default=1, help="1 = also compare a reduced case with the CPU oracle")
     ap.add_argument("--miopen-db", type=int, default=1, help="1 = MIOpen find mode on the shipped find-db (see xai_engine/prepare.py)")
     ap.add_argument("--fuse-bn-relu", type=int, default=1, help="1 = ResNet-50's eval BN + ReLU (+ add) through the fused HIP kernels "
@@ -141,7 +142,7 @@ def main():
         xd.rise_sharded(resnet, x, None, dev, N=min(N, 500), s=s, p1=p1, score_fn=score, batch_size=args.rise_batch,
                         masks=tuple(m[:min(N, 500)] if i < 2 else m for i, m in enumerate(masks)))
         sync(dev); t0 = time.perf_counter()
-        sal = xd.rise_sharded(resnet, x, None, dev, N=N, s=s, p1=p1, score_fn=score, batch_size=args.rise_batch, masks=masks)
+        sal = xd.rise_sharded(resnet, x, None, dev, N=N, s=s, p1=p1, score_fn=score, batch_size=args.rise_batch, masks=masks, streams=args.streams)
         sync(dev); dt = time.perf_counter() - t0
         err = None
         if args.check and rank == 0:
@@ -203,9 +204,9 @@ def main():
 
         def attr_fn(x, target):
             return IG(x, resnet, 50, 50, 1, 0, dev, target).sum(0).abs()      # stays on the device: no drain between images
-        sweep_images(images[:world], resnet, dev, attr_fn, rank=rank, world=world)          # warm-up
+        sweep_images(images[:world], resnet, dev, attr_fn, rank=rank, world=world, streams=args.streams)          # warm-up
         sync(dev); t0 = time.perf_counter()
-        total, used, attr_t = sweep_images(images, resnet, dev, attr_fn, rank=rank, world=world)
+        total, used, attr_t = sweep_images(images, resnet, dev, attr_fn, rank=rank, world=world, streams=args.streams)
         sync(dev); dt = time.perf_counter() - t0
         extra = {}
         if args.check and rank == 0:
