@@ -185,9 +185,10 @@ def run_sweep_workload(args, model, dev, rank, world, prep, miopen_mode, fence, 
             out[m]["images"] = used
         return out
 
-    log(f"sweep workload: {len(images)} images x {methods}; warmup x{args.warmup} (reduced: {2 * world} images)")
+    n_warm = max(2, args.streams) * world
+    log(f"sweep workload: {len(images)} images x {methods}; warmup x{args.warmup} (reduced: {n_warm} images)")
     for _ in range(args.warmup):
-        one_pass(SyntheticImages(2 * world))
+        one_pass(SyntheticImages(n_warm))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -204,7 +205,7 @@ def run_sweep_workload(args, model, dev, rank, world, prep, miopen_mode, fence, 
             "config": {"workload": f"insertion/deletion sweep over a fixed list of {n} synthetic 3x224x224 images (seeds 1000..), ResNet-50 "
                                    f"(seeded random weights), methods {methods}, 224 perturbation steps, batch 50; one step = the whole list",
                        "images": n, "methods": methods, "image_method_pairs_per_s": n * len(methods) * args.steps / dt, "streams": args.streams,
-                       "mode": args.mode, "warmup_step": f"a {2 * world}-image sweep per method (not the full list)", "classifier_prep": prep,
+                       "mode": args.mode, "warmup_step": f"a {n_warm}-image sweep per method (not the full list)", "classifier_prep": prep,
                        "miopen": miopen_mode, "parallelism": f"image i -> rank i % {world}; one all-reduce(SUM) of 12 fp64 (96 B) per method"},
             "metric_means": means}), flush=True)
 
@@ -219,7 +220,7 @@ def sweep_strong_leg(n_images, model, dev, rank, world, fence, max_over_ranks, s
         return sweep_images(imgs, model, dev, lambda x, t: get_CNN_attr(x, None, t, td), img_hw=H, batch_size=50, rank=rank, world=world,
                             streams=streams)
 
-    one_pass(SyntheticImages(2 * world))                  # warm-up: two images per rank (solver selection, allocator, pinned buffers)
+    one_pass(SyntheticImages(max(2, streams) * world))    # warm-up: one image per stream and rank (solver selection, allocator, workspaces)
     fence()
     t0 = time.perf_counter()
     total, used, attr_s = one_pass(SyntheticImages(n_images))

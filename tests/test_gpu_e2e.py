@@ -1159,6 +1159,16 @@ def test_captured_gradcam_replays_match_eager():
     for _ in range(2):                                                  # second call replays the cached graph
         assert rel_inf(get_CNN_attr(xs[1].cpu(), None, torch.tensor(11), tdc), eager) <= 1e-5
     assert len(tdc["_captured_gradcam"]) == 1
+    # the sweep on three streams with captured Grad-CAM: one graph PER STREAM (a replay owns the graph's static buffers), same sums
+    from xai_engine.sweep import sweep_images, KEYS
+    images = [torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(60 + i)) for i in range(7)]
+    tds = dict(td, device_maps=True, capture_gradcam=True)
+    s3, used, _ = sweep_images(images, model, DEV, lambda x, t: get_CNN_attr(x, None, t, tds), img_hw=64, batch_size=25, streams=3)
+    assert used == 7 and len(tds["_captured_gradcam"]) == 3
+    te = dict(td, device_maps=True)
+    s1, _, _ = sweep_images(images, model, DEV, lambda x, t: get_CNN_attr(x, None, t, te), img_hw=64, batch_size=25)
+    for k in KEYS:                                       # deterministic solvers (conftest): a replay computes what the eager launch computes
+        assert s3[k] == s1[k], (k, s3[k], s1[k])
 
 
 
