@@ -121,11 +121,11 @@ def ig_step_sharded(input, model, steps, alpha_star, baseline, device, target_cl
     / n_use * (x - baseline).  Returns (C,H,W) on every rank.  The sum is associated per rank, so the
     result equals the single-process IG to rounding (<= 1e-6 relative), not bitwise."""
     from . import kernels as K
-    from .ig import _prep, getGradientsParallel
+    from .ig import _prep, _uniform_alphas, getGradientsParallel
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     dev, x, base = _prep(input, baseline, device)
-    alphas = torch.linspace(0, 1, steps).to(dev)
+    alphas = _uniform_alphas(steps, dev)
     lo, hi = step_range(steps, rank, world)
     n_mine = hi - lo
     logits = torch.zeros(steps, dtype=torch.float32, device=dev)

@@ -58,6 +58,22 @@ def input_grad(input, model, target_class):
     return gradient
 
 
+_ALPHAS = {}
+
+
+def _uniform_alphas(steps, dev):
+    """linspace(0, 1, steps) computed on the HOST like the reference (saliencyMethods.py:21; ATen's CPU fill, not the device's, decides
+    the last bit) and kept on the device: uploading 50 floats from pageable memory on every call blocks the host until the
+    stream has drained, which serialises callers that overlap attributions on several streams."""
+    key = (int(steps), str(dev))
+    t = _ALPHAS.get(key)
+    if t is None:
+        t = torch.linspace(0, 1, steps).to(dev)
+        torch.cuda.current_stream(dev).synchronize()          # once: every stream may read it from here on
+        _ALPHAS[key] = t
+    return t
+
+
 def _prep(input, baseline, device):
     dev = hip_device(device)
     x = input.to(dev, torch.float32).contiguous()
@@ -116,7 +132,7 @@ def IG(input, model, steps, batch_size, alpha_star, baseline, device, target_cla
         print("steps must be evenly divisible by batch size: " + str(batch_size) + "!")
         return 0, 0, 0, 0
     dev, x, base = _prep(input, baseline, device)
-    alphas = torch.linspace(0, 1, steps).to(dev)          # computed on the host, as the reference does
+    alphas = _uniform_alphas(steps, dev)                  # computed on the host, as the reference does
     if alpha_star == 1:
         return K.ig_finish(_path_sum(x, base, alphas, model, batch_size, target_class), steps, x, base)[0]
     grads, logits = _path(x, base, alphas, model, batch_size, target_class)
@@ -192,7 +208,7 @@ def IDGI(input, model, steps, batch_size, baseline, device, target_class):
         print("steps must be evenly divisible by batch size: " + str(batch_size) + "!")
         return 0, 0, 0, 0
     dev, x, base = _prep(input, baseline, device)
-    grads, logits = _path(x, base, torch.linspace(0, 1, steps).to(dev), model, batch_size, target_class)
+    grads, logits = _path(x, base, _uniform_alphas(steps, dev), model, batch_size, target_class)
     g = grads[0]
     return K.idgi_accum(g, logits[0].contiguous(), K.sumsq(g))
 
@@ -234,7 +250,7 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
     B = x.shape[0]
     dev = x.device
     base = baseline.to(dev, torch.float32).contiguous() if torch.is_tensor(baseline) else float(baseline)
-    alphas = torch.linspace(0, 1, steps).to(dev)
+    alphas = _uniform_alphas(steps, dev)
     if buffered is None:
         buffered = alpha_star != 1 or grads_buffer is not None or event_sink is not None
     if not buffered and alpha_star != 1:

@@ -128,6 +128,16 @@ def main():
     cm = K.rownorm(cs)
     ms = timeit(lambda: K.causal_apply(x[0].contiguous(), cm, noise, 0.1))
     rep("causal_apply 64 masks", 64 * (3 * N + H * W) * 4 + 4 * N, ms, "read noise+masks, write 2N images")
+    # K16 (score-weighted mask sums of TIS / ViT-CX): one read of the stack; before round 3 two K2 launches read it twice
+    pf = torch.rand(64, device=DEV)
+    ms = timeit(lambda: K.masked_sums(cm, pf))
+    rep("masked_sums 64 x 50176 (ViT-CX)", (64 + 2) * H * W * 4, ms, "one pass; stack cache-resident")
+    ones_p = torch.ones((1, 1, H * W), device=DEV)
+    ms = timeit(lambda: (K.ig_accum(cm.view(1, 64, 1, H * W), ones_p, 0.0, w1=pf.view(1, 64)), K.ig_accum(cm.view(1, 64, 1, H * W), ones_p, 0.0)))
+    rep("  (same via two K2 launches)", 2 * (64 + 2) * H * W * 4, ms, "round 2's form")
+    tm = (torch.rand(1024, 196, device=DEV) < 0.5).float(); ts = torch.rand(1024, device=DEV)
+    ms = timeit(lambda: K.masked_sums(tm, ts))
+    rep("masked_sums 1024 x 196 (TIS)", (1024 + 2) * 196 * 4, ms, "49 lanes walk 1024 rows: latency-bound")
     # K15 (classifier-side fusion): layer1 activation of the benchmark's pass, 100 x 256 x 56 x 56
     from xai_engine.prepare import BN_VARIANT
     act = torch.randn(100, 256, 56, 56, device=DEV); idt = torch.randn_like(act); gy = torch.randn_like(act)
