@@ -12,6 +12,7 @@ from xai_engine.zoo import resnet50
 from xai_engine.prepare import fuse_bn_relu, use_tuned_miopen_db
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "deterministic"
+OWN = len(sys.argv) > 2 and sys.argv[2] == "own"      # capture every slot's graph on its OWN stream (torch.cuda.graph's default capture stream is shared)
 dev = torch.device("cuda:0")
 if mode == "finddb":
     assert use_tuned_miopen_db(0)
@@ -41,7 +42,7 @@ class Slot:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **({"stream": side} if OWN else {})):
             self.g = self.run()
 
     def run(self):
@@ -90,7 +91,7 @@ for ipp in (1, 2):
         while len(slots) < ns:
             slots.append(Slot(ipp))
         out, dt, host = timeit(lambda: graph_step(slots[:ns], ipp))
-        print(json.dumps({"mode": mode, "flow": "graph", "images_per_pass": ipp, "streams": ns, "ms_per_step": dt * 1e3, "host_enqueue_ms": host * 1e3, "attr_per_s": B / dt,
+        print(json.dumps({"mode": mode, "flow": "graph", "capture_on_own_stream": OWN, "images_per_pass": ipp, "streams": ns, "ms_per_step": dt * 1e3, "host_enqueue_ms": host * 1e3, "attr_per_s": B / dt,
                           "bit_identical_to_eager_1_stream": bool(torch.equal(out[0], ref[ipp])),
                           "rel_inf": float((out[0] - ref[ipp]).abs().max() / ref[ipp].abs().max())}), flush=True)
         if ns in (2, 3, 4):
