@@ -23,7 +23,8 @@ xai_engine.load_library()
 plain = resnet50(seed=0).to(dev)
 B, S = 32, 50
 x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(2)).to(dev)
-model = fuse_bn_relu(plain, verify=x[:2], fork_residual=True)
+model = plain if os.environ.get("XAI_EXP_PLAIN") else fuse_bn_relu(plain, verify=x[:2], fork_residual=True)
+ONLY_IPP = [int(v) for v in os.environ.get("XAI_EXP_IPP", "1,2").split(",")]
 with torch.no_grad():
     targets = plain(x).argmax(1)
 grads = torch.empty((B, S, 3, 224, 224), device=dev)
@@ -82,12 +83,12 @@ def timeit(f, n=3):
 
 
 ref = {}
-for ipp in (1, 2):
+for ipp in ONLY_IPP:
     out, dt, host = timeit(lambda: ig_batch(x, model, targets, steps=S, images_per_pass=ipp, want_abs=True, grads_buffer=grads))
     ref[ipp] = out[0].clone()
     print(json.dumps({"mode": mode, "flow": "eager", "images_per_pass": ipp, "streams": 1, "ms_per_step": dt * 1e3, "host_enqueue_ms": host * 1e3, "attr_per_s": B / dt}), flush=True)
     slots = []
-    for ns in (1, 2, 3, 4, 6):
+    for ns in (1, 2, 3):
         while len(slots) < ns:
             slots.append(Slot(ipp))
         out, dt, host = timeit(lambda: graph_step(slots[:ns], ipp))

@@ -141,6 +141,23 @@ def test_classifier_passes_on_several_streams_are_bit_identical_to_one_stream(re
     assert 5 * 0.008 < t1 < 5 * 0.2 and 5 * 0.008 < t3 < 5 * 0.5, (t1, t3)
 
 
+def test_captured_gradcam_graphs_replayed_concurrently_on_three_streams(resnet):
+    """Grad-CAM as a hipGraph per stream (sweep_images(streams=3) + capture_gradcam): three graphs of the full ResNet-50 forward +
+    backward-to-layer4 replay CONCURRENTLY on three streams.  Concurrent replays of captured classifier passes are not a given
+    (profiles/r03_exp_ig_graph_streams.jsonl: per-pass IG graphs at batch 50 corrupt each other), so the sums are held, bit for bit,
+    to the eager one-stream sweep."""
+    from xai_engine.sweep import sweep_images, get_CNN_attr, KEYS
+    td = {"models": [resnet], "img_hw": 224, "batch_size": 50, "device": DEV, "device_maps": True, "attr_func": "gc"}
+    images = [_image(2000 + i) for i in range(6)]
+    eager, used, _ = sweep_images(images, resnet, DEV, lambda x, t: get_CNN_attr(x, None, t, td), img_hw=224, batch_size=50)
+    tdc = dict(td, capture_gradcam=True)
+    for rep in range(2):
+        cap, used_c, _ = sweep_images(images, resnet, DEV, lambda x, t: get_CNN_attr(x, None, t, tdc), img_hw=224, batch_size=50, streams=3)
+        assert used == used_c == 6 and len(tdc["_captured_gradcam"]) == 3
+        for k in KEYS:
+            assert cap[k] == eager[k], (rep, k, cap[k], eager[k])
+
+
 def test_config3_rise_resnet50_200_masks(resnet):
     """configs[2]: RISE on ResNet-50 (200 of the 8000 masks; the mask range split of the multi-GPU run is exercised too)."""
     from xai_engine.rise import rise, draw_masks
