@@ -741,9 +741,11 @@ assert (rank, world) == (0, 1) and dev.type == "cuda"
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 assert dist.get_backend() == "nccl"
 # the three messages of the sharded paths, with their dtypes and sizes, through RCCL itself (one rank: the values must come back unchanged)
-vec = torch.arange(11, dtype=torch.float64, device=dev) * 0.5          # 88 B: 10 metric sums + count
+vec = torch.arange(12, dtype=torch.float64, device=dev) * 0.5          # 96 B: 10 metric sums + count + seconds in attribution
 dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-assert vec.cpu().tolist() == [0.5 * i for i in range(11)]
+assert vec.cpu().tolist() == [0.5 * i for i in range(12)]
+rows = torch.rand(1001, 11, dtype=torch.float64, device=dev)           # 88 KB: the per-image rows of a 1000-image reference-Counter sweep
+keep = rows.clone(); dist.all_reduce(rows, op=dist.ReduceOp.SUM); assert torch.equal(rows, keep)
 part = torch.rand(224, 224, dtype=torch.float64, device=dev)           # 401 KB: RISE partial map
 keep = part.clone(); dist.all_reduce(part, op=dist.ReduceOp.SUM); assert torch.equal(part, keep)
 acc = torch.rand(1, 3, 224, 224, device=dev)                           # 602 KB: IG step-sharded partial sum
@@ -754,6 +756,8 @@ t = torch.tensor([1.25], dtype=torch.float64, device=dev); dist.all_reduce(t, op
 dist.barrier()
 total, used = sweep.reduce_counters({k: 1.0 for k in sweep.KEYS}, 3, dev)   # world 1: no collective, same values
 assert used == 3 and all(v == 1.0 for v in total.values())
+got_rows, flags, secs = sweep.gather_rows({0: [1.0] * 10, 2: [2.0] * 10}, 3, dev, attr_seconds=0.5)   # world 1 inside an initialised nccl job
+assert flags.tolist() == [True, False, True] and got_rows[2, 0] == 2.0 and secs == 0.5
 dist.destroy_process_group()
 print("rccl one rank ok")
 '''
