@@ -16,8 +16,9 @@ reported time is the MAX over ranks.
 The headline `value` is measured in the PARITY configuration (`--mode parity`, the default): MIOpen immediate mode with
 deterministic solvers only and ONE image = the reference's 50-interpolant batch per classifier pass (saliencyMethods.py:40-46)
 -- the configuration every parity test runs and the 1e-5 claim is made on; its classifier passes are run-to-run bit-identical.
-Consecutive passes are queued round-robin on `--streams` HIP streams (default 3): the same kernels on the same shapes, so the
-maps are bit-identical to the one-stream run, while the low-occupancy layers of one pass overlap another pass's work.
+Consecutive passes are queued round-robin on `--streams` HIP streams (default 3), one host thread per stream, backward passes taking
+turns (xai_engine/streams.py): the same kernels on the same shapes, so the maps are bit-identical to the one-stream run, while the
+forward of one pass overlaps the backward of another.
 `--mode throughput` is the fastest configuration instead (the shipped MIOpen find-db's solvers, which include split-K kernels
 that are not run-to-run reproducible, and 2 images per pass); at N = 1 the default run measures it in a child process and
 reports it as `throughput_mode`.
@@ -296,7 +297,8 @@ def main():
 
     import xai_engine
     xai_engine.load_library()                      # no extension -> no benchmark
-    from xai_engine.ig import ig_batch, IG, _side_streams
+    from xai_engine.ig import ig_batch, IG
+    from xai_engine.streams import run_on_streams
     from xai_engine.zoo import resnet50
 
     torch.backends.cudnn.benchmark = bool(args.miopen_find) or tuned
@@ -403,18 +405,8 @@ def main():
         def api_serial():
             return [IG(x[i:i + 1], model, STEPS_IG, 50, 1, 0, dev, targets[i]) for i in range(B)]
 
-        def api_streams():
-            main_s = torch.cuda.current_stream(dev)
-            side = _side_streams(dev, args.streams)
-            for s_ in side:
-                s_.wait_stream(main_s)
-            outs = []
-            for i in range(B):
-                with torch.cuda.stream(side[i % len(side)]):
-                    outs.append(IG(x[i:i + 1], model, STEPS_IG, 50, 1, 0, dev, targets[i]))
-            for s_ in side:
-                main_s.wait_stream(s_)
-            return outs
+        def api_streams():                              # one host thread per stream (xai_engine/streams.py); IG's backward passes take turns
+            return run_on_streams(dev, args.streams, [lambda i=i: IG(x[i:i + 1], model, STEPS_IG, 50, 1, 0, dev, targets[i]) for i in range(B)])
 
         api_serial()
         da = timed(api_serial, 1)
@@ -425,7 +417,8 @@ def main():
             api["on_streams"] = {"value": world * B / ds, "unit": "attributions/s", "ms_per_step": ds * 1e3, "steps": 1, "streams": args.streams}
         api["note"] = (f"the same {B} images as {B} calls of IG(input, model, 50, 50, 1, 0, device, target) -- the reference's one-image signature "
                        "(alpha_star == 1 streams the step gradients into a (C,H,W) accumulator: no gradient buffer, no filing copy); `serial` = one "
-                       "call after the other on one stream, `on_streams` = the caller issues the calls round-robin on HIP streams")
+                       "call after the other on one stream, `on_streams` = the caller issues the calls from one host thread per HIP stream "
+                       "(xai_engine.streams.run_on_streams)")
         log("one-image API: " + ", ".join(f"{k} {v['ms_per_step']:.1f} ms" for k, v in api.items() if isinstance(v, dict)))
 
         if model is not plain_model and world == 1:       # the same workload on the classifier exactly as given, for the record

@@ -10,16 +10,18 @@ import torch
 
 from . import kernels as K
 from ._lib import XaiHipError
+from .streams import backward_turn
 
 
 def _grad_of_activation(score, act):
     """d score / d act.  A classifier prepared with prepare.fuse_bn_relu(fork_residual=True) hands a block output on as two
     tensors on one storage (act and act._xai_alias); the gradient of the activation is the sum over both handles."""
     alias = getattr(act, "_xai_alias", None)
-    if alias is None:
-        (grad,) = torch.autograd.grad(score, act)
-        return grad
-    ga, gb = torch.autograd.grad(score, [act, alias], allow_unused=True)
+    with backward_turn(act.device):                       # streams.py: backward passes on autograd's shared device thread take turns
+        if alias is None:
+            (grad,) = torch.autograd.grad(score, act)
+            return grad
+        ga, gb = torch.autograd.grad(score, [act, alias], allow_unused=True)
     if ga is None or gb is None:
         return ga if gb is None else gb
     return ga + gb
@@ -197,5 +199,6 @@ class CapturedGradCam:
             self.x.copy_(inputs, non_blocking=True)
             t = target if torch.is_tensor(target) else torch.tensor(target)
             self.target.copy_(t.to(self.dev, torch.int64).reshape(-1).expand(self.x.shape[0]), non_blocking=True)
-        self.graph.replay()
+        with backward_turn(self.dev):                     # the graph holds backward kernels (streams.py)
+            self.graph.replay()
         return self.sal.clone()

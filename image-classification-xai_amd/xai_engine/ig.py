@@ -6,10 +6,13 @@ Mirrors util/attribution_methods/saliencyMethods.py of the reference (signatures
 shapes, the print-and-return-zeros error convention); `ig_batch` is the multi-image fast
 path the reference does not have.
 """
+import contextlib
+
 import torch
 
 from . import kernels as K
 from ._lib import XaiHipError
+from .streams import backward_turn, run_on_streams
 
 
 def hip_device(device):
@@ -40,7 +43,8 @@ def getGradientsParallel(inputs, model, target_class):
     """d logit[target] / d inputs for a batch; raw logits (reference saliencyMethods.py:209-215)."""
     output = _logits_of(model(inputs))
     scores = _select_class(output, target_class)
-    gradients = torch.autograd.grad(scores, inputs, grad_outputs=torch.ones_like(scores))[0]
+    with backward_turn(inputs.device) if inputs.is_cuda else contextlib.nullcontext():      # streams.py
+        gradients = torch.autograd.grad(scores, inputs, grad_outputs=torch.ones_like(scores))[0]
     return gradients.detach().squeeze(), scores.detach().squeeze()
 
 
@@ -213,17 +217,6 @@ def IDGI(input, model, steps, batch_size, baseline, device, target_class):
     return K.idgi_accum(g, logits[0].contiguous(), K.sumsq(g))
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_streams(dev, n):
-    """n HIP streams per device, created once (stream creation is not free and hipGraph-unfriendly)."""
-    have = _SIDE_STREAMS.setdefault(str(dev), [])
-    while len(have) < n:
-        have.append(torch.cuda.Stream(dev))
-    return have[:n]
-
-
 def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_pass=4, want_abs=False,
              grads_buffer=None, event_sink=None, buffered=None, streams=1):
     """Multi-image IG / Left-IG: x (B,C,H,W) on a HIP device, targets (B,) long.
@@ -238,10 +231,11 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
                  HBM traffic.
     `buffered`: None = buffered exactly when it has to be (alpha_star != 1) or the caller asked for it by passing
     `grads_buffer` / `event_sink`.
-    `streams` > 1: consecutive classifier passes are queued round-robin on that many HIP streams, so the low-occupancy layers
-    of one pass (7x7 feature maps, the stem's backward) overlap another pass's work.  Every pass still launches the same kernels
-    on the same shapes and writes disjoint rows, so the result is bit-identical to `streams=1`
-    (tests/test_gpu_e2e.py::test_ig_batch_passes_on_several_streams).
+    `streams` > 1: consecutive classifier passes are queued round-robin on that many HIP streams, each driven by its own host
+    thread, and their backward passes take turns (xai_engine/streams.py: the two rules that make this safe with PyTorch-ROCm's
+    per-handle library workspaces) -- the forward of one pass overlaps the backward of another.  Every pass still launches the
+    same kernels on the same shapes and writes disjoint rows, so the result is bit-identical to `streams=1`
+    (tests/test_gpu_configs.py::test_classifier_passes_on_several_streams_are_bit_identical_to_one_stream).
     `event_sink`: optional list that receives (start, end, kernel_start, kernel_stop) torch.cuda.Events of the
     accumulation launch: a pair bracketing it and a pair stamped by the dispatch itself (used by bench.py for the roofline figure)."""
     if not x.is_cuda:
@@ -271,7 +265,8 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
         flat = imgs.view((-1,) + tuple(x.shape[1:])).requires_grad_(True)
         out = _logits_of(model(flat))
         scores = out.gather(1, targets[lo:hi].repeat_interleave(steps).unsqueeze(1)).squeeze(1)
-        (g,) = torch.autograd.grad(scores, flat, grad_outputs=torch.ones_like(scores))
+        with backward_turn(dev):
+            (g,) = torch.autograd.grad(scores, flat, grad_outputs=torch.ones_like(scores))
         g = g.contiguous()
         if buffered:
             K.store_grads(g, grads_buffer[lo:hi])
@@ -287,17 +282,7 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
         for lo, hi in spans:
             one_pass(lo, hi)
     else:
-        main = torch.cuda.current_stream(dev)
-        side = _side_streams(dev, n_streams)
-        ready = torch.cuda.Event()
-        ready.record(main)                                   # x, alphas, targets, the zeroed accumulator
-        for st in side:
-            st.wait_event(ready)
-        for i, (lo, hi) in enumerate(spans):
-            with torch.cuda.stream(side[i % n_streams]):
-                one_pass(lo, hi)
-        for st in side:
-            main.wait_stream(st)
+        run_on_streams(dev, n_streams, [lambda lo=lo, hi=hi: one_pass(lo, hi) for lo, hi in spans])
     if not buffered:
         return K.ig_finish(acc, steps, x, base, want_abs=want_abs)
     n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)

@@ -55,8 +55,9 @@ def rise(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=N
     score.  Extensions (keyword-only): `score_fn(batch) -> (B,)` for a plain classifier,
     `masks=(grid, shifts, cell)` to reuse a draw, `mask_range=(lo, hi)` to process a shard of the
     masks (multi-GPU), `return_partial` to get the un-rounded fp64 partial sum for an all-reduce,
-    `streams` > 1 to queue consecutive mask batches round-robin on that many HIP streams (each with its own batch buffer; the
-    batches write disjoint score slices, so the map is bit-identical to `streams=1`).
+    `streams` > 1 to queue consecutive mask batches round-robin on that many HIP streams, each driven by its own host thread
+    (xai_engine/streams.py) with its own batch buffer; the batches write disjoint score slices, so the map is bit-identical to
+    `streams=1`.
     """
     dev = hip_device(device)
     H, W = int(image.shape[-2]), int(image.shape[-1])
@@ -82,21 +83,16 @@ def rise(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=N
             feats = F.normalize(model.encode_image(masked), dim=-1)
             scores[i:j] = (feats @ txt_embedding.T).reshape(-1).float()
 
-    with torch.no_grad():
-        if n_streams == 1:
-            for i, j in spans:
-                one_batch(i, j, bufs[0])
-        else:
-            from .ig import _side_streams
-            main = torch.cuda.current_stream(dev)
-            side = _side_streams(dev, n_streams)
-            for st in side:
-                st.wait_stream(main)                            # image, grid, shifts, the buffers
-            for k, (i, j) in enumerate(spans):
-                with torch.cuda.stream(side[k % n_streams]):
-                    one_batch(i, j, bufs[k % n_streams])
-            for st in side:
-                main.wait_stream(st)
+    def job(k, i, j):
+        with torch.no_grad():                                   # grad mode is thread-local: a stream worker starts with it enabled
+            one_batch(i, j, bufs[k % n_streams])
+
+    if n_streams == 1:
+        for k, (i, j) in enumerate(spans):
+            job(k, i, j)
+    else:
+        from .streams import run_on_streams                     # one host thread per stream (streams.py); forward only
+        run_on_streams(dev, n_streams, [lambda k=k, i=i, j=j: job(k, i, j) for k, (i, j) in enumerate(spans)])
     acc = torch.zeros((H, W), dtype=torch.float64, device=dev)
     if n > 0:
         K.rise_accum(g_all, sh_all, scores, cell, H, W, 1.0 / N / p1, acc=acc)

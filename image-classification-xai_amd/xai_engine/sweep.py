@@ -393,9 +393,10 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     images' ten numbers, ONE all-reduce of the zero-padded (images, 11) matrix hands every rank all of them (`gather_rows`), and
     the replay runs over them in file order -- the same Counter for every world size.  The Counter returned then holds only
     the surviving keys, in the reference's order; `write_csv(..., reference_counter=True)` writes exactly those rows.
-    `streams` > 1 (fused flow): consecutive images are queued round-robin on that many HIP streams -- attribution, ranking and the
-    three step sequences of one image form a serial chain of mostly small or low-occupancy launches, so the chains of `streams`
-    images overlap on the chip.  Every image still runs the same kernels on the same shapes and the per-image Counters are folded
+    `streams` > 1 (fused flow): consecutive images are queued round-robin on that many HIP streams, each driven by its own host
+    thread (xai_engine/streams.py; `attr_fn` and the image access then run on those threads, in no particular order) --
+    attribution, ranking and the three step sequences of one image form a serial chain of mostly small or low-occupancy launches,
+    so the chains of `streams` images overlap on the chip.  Every image still runs the same kernels on the same shapes and the per-image Counters are folded
     in image order, so the sums are bit-identical to `streams=1` (tests/test_gpu_e2e.py::test_sweep_images_on_several_streams).
     The third return value, seconds in attribution, is measured with HIP events on the image's stream when the map stays on the
     device (the reference times a finished attribution, evaluatePerturbation.py:581-590; the host clock around an asynchronous
@@ -421,53 +422,60 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
             st.save(checkpoint)
 
     n_streams = max(1, int(streams)) if fused else 1
-    side = None
-    main_stream = torch.cuda.current_stream(dev)
+    ws = None
     if n_streams > 1:
-        from .ig import _side_streams
-        side = _side_streams(dev, n_streams)
-        for s_ in side:                                  # weights, blur taps: whatever the caller's stream has queued so far
-            s_.wait_stream(torch.cuda.current_stream(dev))
-    pending = collections.deque()                        # (handle, pos, attribution timer) of the images whose device work is in flight
+        from .streams import workers, join
+        ws = workers(dev, n_streams)                     # one host thread per stream (streams.py)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))     # weights, blur taps: whatever the caller's stream has queued so far
+    pending = collections.deque()                        # (future or result, pos) of the images whose device work is in flight
     failed = None
 
+    def device_part(pos):
+        """Everything of one image that runs on the device, queued on the current stream of the calling thread:
+        -> (handle for `finish` or the finished Counter, attribution timer or None)."""
+        x = images[mine[pos]]
+        if ws is not None:
+            torch.cuda.current_stream(dev).wait_event(ready)
+        if fused and not x.is_cuda:
+            # one upload through pinned memory, queued behind the previous image's work: a pageable .to(dev) blocks the
+            # host until the stream has drained, which would undo the pipelining
+            x = x.to(torch.float32).contiguous().pin_memory().to(dev, non_blocking=True)
+        with torch.no_grad():
+            target = _logits_of(model(x.to(dev))).argmax(1)[0]
+        timer = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        t0 = time.time()
+        timer[0].record(torch.cuda.current_stream(dev))
+        sal = attr_fn(x, target)
+        timer[1].record(torch.cuda.current_stream(dev))
+        host_seconds = None
+        if not (torch.is_tensor(sal) and sal.is_cuda):
+            host_seconds = time.time() - t0              # a host map: attr_fn has waited for the device itself
+            timer = None
+        if fused:
+            return sweep.launch(x, sal), timer, host_seconds
+        if timer is not None:
+            timer[1].synchronize()
+            host_seconds, timer = timer[0].elapsed_time(timer[1]) * 1e-3, None
+        return run_perturbation(x.cpu(), sal, td, blur=blur), timer, host_seconds
+
     def finish_oldest():
-        handle, pos, timer = pending.popleft()
-        c = sweep.finish(handle)
+        job, pos = pending.popleft()
+        out, timer, host_seconds = job.result() if ws is not None else job
+        c = sweep.finish(out) if fused else out
         if timer is not None:                            # the events lie before `done` on the same stream: complete by now
             st.attr_time += timer[0].elapsed_time(timer[1]) * 1e-3
+        if host_seconds is not None:
+            st.attr_time += host_seconds
         fold(c, pos)
 
     try:
         for pos in range(st.next_pos, len(mine)):
-            x = images[mine[pos]]
-            with (torch.cuda.stream(side[pos % n_streams]) if side else contextlib.nullcontext()):
-                if side and x.is_cuda:                   # a device image the caller produced on ITS stream a moment ago
-                    torch.cuda.current_stream(dev).wait_stream(main_stream)
-                if fused and not x.is_cuda:
-                    # one upload through pinned memory, queued behind the previous image's work: a pageable .to(dev) blocks the
-                    # host until the stream has drained, which would undo the pipelining
-                    x = x.to(torch.float32).contiguous().pin_memory().to(dev, non_blocking=True)
-                with torch.no_grad():
-                    target = _logits_of(model(x.to(dev))).argmax(1)[0]
-                timer = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                t0 = time.time()
-                timer[0].record(torch.cuda.current_stream(dev))
-                sal = attr_fn(x, target)
-                timer[1].record(torch.cuda.current_stream(dev))
-                if not (torch.is_tensor(sal) and sal.is_cuda):
-                    st.attr_time += time.time() - t0     # a host map: attr_fn has waited for the device itself
-                    timer = None
-                if fused:
-                    # `n_streams` images deep: queue this image's device work, then do the oldest image's host arithmetic
-                    pending.append((sweep.launch(x, sal), pos, timer))
-                    while len(pending) > n_streams:
-                        finish_oldest()
-                else:
-                    if timer is not None:
-                        timer[1].synchronize()
-                        st.attr_time += timer[0].elapsed_time(timer[1]) * 1e-3
-                    fold(run_perturbation(x.cpu(), sal, td, blur=blur), pos)
+            # `n_streams` images deep: queue this image's device work (on its stream's worker thread), then do the oldest image's
+            # host arithmetic while the device runs
+            pending.append((ws[pos % n_streams].submit(lambda pos=pos: device_part(pos)) if ws is not None else device_part(pos), pos))
+            while len(pending) > (n_streams if fused else 0):
+                finish_oldest()
     except BaseException as e:
         failed = e
         raise
@@ -479,6 +487,8 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
                 if failed is None:                       # nothing else went wrong: this IS the error
                     raise
                 break                                    # a device error already in flight makes the fold fail too: report the original
+        if ws is not None:
+            join(dev, ws)
     if reference_counter:
         if len(st.rows) != st.used:
             raise CheckpointMismatch("this checkpoint was written without reference_counter: it holds sums only, not the per-image "

@@ -16,6 +16,16 @@ import torch
 
 from . import kernels as K
 from .ig import hip_device
+from .streams import backward_turn
+
+
+def _backward(score):
+    """score.backward() as one turn of the device's backward passes (xai_engine/streams.py)"""
+    if score.is_cuda:
+        with backward_turn(score.device):
+            score.backward()
+    else:
+        score.backward()
 
 
 class Baselines:
@@ -38,7 +48,7 @@ class Baselines:
         """Clamped head-mean CLS attention gradient (reference :146-157)."""
         x = input.to(device).detach().requires_grad_(True)
         output = self.model(x, register_hook=True)
-        output[0][target_class].sum().backward()
+        _backward(output[0][target_class].sum())
         grad = self.model.blocks[layer].attn.get_attn_gradients().mean(1)[:, 0, 1:].clamp(0)
         side = int(np.sqrt(grad.shape[-1]))
         return grad.reshape(-1, side, side)
@@ -50,7 +60,7 @@ class Baselines:
         alphas = torch.from_numpy(np.linspace(0, 1, steps)).to(dev, torch.float32)    # float64 linspace rounded once
         scaled = (x * alphas.reshape(steps, 1, 1, 1)).detach().requires_grad_(True)   # (steps,C,H,W): input * alpha
         output = self.model(scaled, register_hook=True)
-        output[:, target_class].sum().backward()
+        _backward(output[:, target_class].sum())
         g = self._last_attn().get_attn_gradients()                                    # (steps, heads, S, S)
         heads, S = g.shape[1], g.shape[-1]
         cls_rows = g[:, :, 0, :].contiguous().reshape(1, steps, heads, S)              # the only rows that are used
@@ -162,7 +172,7 @@ def _generate_transition_attention_maps(self, input, target_class, start_layer=0
     x = input.to(dev, torch.float32)
     x0 = x.detach().requires_grad_(True)
     out = self.model(x0, register_hook=True)
-    out[0][target_class].sum().backward()
+    _backward(out[0][target_class].sum())
     blocks = self.model.blocks
     maps = [blk.attn.get_attention_map().detach() for blk in blocks]
     grad0 = blocks[-1].attn.get_attn_gradients()
@@ -174,7 +184,7 @@ def _generate_transition_attention_maps(self, input, target_class, start_layer=0
     alphas = torch.from_numpy(np.linspace(0, 1, steps)).to(dev, torch.float32)
     scaled = (x * alphas.reshape(steps, 1, 1, 1)).detach().requires_grad_(True)
     output = self.model(scaled, register_hook=True)
-    output[:, target_class].sum().backward()
+    _backward(output[:, target_class].sum())
     g = blocks[-1].attn.get_attn_gradients()                                   # (steps, h, s, s)
     last_map = blocks[-1].attn.get_attention_map()[-1:].detach()
     if with_integral:
@@ -199,7 +209,7 @@ def _attn_attr(self, input, target_class, start_layer=0, device="cuda:0"):
     dev = hip_device(device)
     x0 = input.to(dev, torch.float32).detach().requires_grad_(True)
     out = self.model(x0, register_hook=True)
-    out[0][target_class].sum().backward()
+    _backward(out[0][target_class].sum())
     blocks = self.model.blocks
     b, h, s, _ = blocks[-1].attn.get_attention_map().shape
     states = blocks[-1].attn.get_attention_map().detach().mean(1)[:, 0, :].reshape(b, 1, s)
@@ -220,7 +230,7 @@ def _bidirectional(self, input, target_class, steps=20, start_layer=4, samples=2
     x = input.to(dev, torch.float32)
     x0 = x.detach().requires_grad_(True)
     out = self.model(x0, register_hook=True)
-    out[0][target_class].sum().backward()
+    _backward(out[0][target_class].sum())
     blocks = self.model.blocks
     b, num_head, num_tokens, _ = blocks[-1].attn.get_attention_map().shape
     R = torch.eye(num_tokens, num_tokens, device=dev).expand(b, num_tokens, num_tokens)
@@ -253,7 +263,7 @@ def _bidirectional(self, input, target_class, steps=20, start_layer=4, samples=2
     alphas = torch.from_numpy(np.linspace(0, 1, steps)).to(dev, torch.float32)
     scaled = (x * alphas.reshape(steps, 1, 1, 1)).detach().requires_grad_(True)
     output = self.model(scaled, register_hook=True)
-    output[:, target_class].sum().backward()
+    _backward(output[:, target_class].sum())
     g = blocks[-1].attn.get_attn_gradients().contiguous()                      # (steps, heads, S, S)
     n = num_head * num_tokens * num_tokens
     ones = torch.ones((1, 1, n), dtype=torch.float32, device=dev)

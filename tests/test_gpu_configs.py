@@ -141,6 +141,56 @@ def test_classifier_passes_on_several_streams_are_bit_identical_to_one_stream(re
     assert 5 * 0.008 < t1 < 5 * 0.2 and 5 * 0.008 < t3 < 5 * 0.5, (t1, t3)
 
 
+def test_stream_workers_avoid_the_one_thread_two_streams_hazard(resnet):
+    """xai_engine/streams.py's rule, on the launch that exposes the hazard: the backward-data of ResNet-50's layer4.0.conv3 at batch
+    50 (a rocBLAS split-K GEMM inside MIOpen) goes wrong in > 90 % of the launches when ONE host thread issues it alternately on two
+    streams (profiles/r03_exp_bwd_concurrency_variants.jsonl).  Issued by two stream workers -- one host thread, one handle set per
+    stream, autograd inline -- every result must equal the serial one bit for bit; so must the one-thread form under
+    `backward_turn`'s device-side chain.  How often the unprotected one-thread form fails on this box is recorded, not asserted
+    (it is the library stack's behaviour, not this library's)."""
+    from xai_engine.streams import workers, backward_turn
+    conv = resnet.layer4[0].conv3
+    shape, gshape = (50, 512, 7, 7), (50, 2048, 7, 7)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    ws = workers(torch.device(DEV), 2)
+
+    def grad(x, gy):
+        xr = x.detach().requires_grad_(True)
+        (gx,) = torch.autograd.grad(conv(xr), xr, gy)
+        return gx
+
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    wrong = {"workers": 0, "one_thread_with_turns": 0, "one_thread_unprotected": 0}
+    reps, trials = 8, 25
+    for _ in range(trials):
+        xs = [torch.randn(shape, device=DEV, generator=gen) for _ in range(2)]
+        gys = [torch.randn(gshape, device=DEV, generator=gen) for _ in range(2)]
+        want = [grad(xs[k], gys[k]) for k in range(2)]
+        torch.cuda.synchronize()
+        futs = [ws[k].submit(lambda k=k: [grad(xs[k], gys[k]) for _ in range(reps)]) for k in range(2)]
+        got = [f.result() for f in futs]
+        torch.cuda.synchronize()
+        wrong["workers"] += sum(not torch.equal(a, want[k]) for k in range(2) for a in got[k])
+        for key in ("one_thread_with_turns", "one_thread_unprotected"):
+            got = [[], []]
+            for _ in range(reps):
+                for k in range(2):
+                    with torch.cuda.stream(streams[k]):
+                        if key == "one_thread_with_turns":
+                            with backward_turn(DEV):
+                                got[k].append(grad(xs[k], gys[k]))
+                        else:
+                            got[k].append(torch.ops.aten.convolution_backward(gys[k], xs[k], conv.weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                                              [True, False, False])[0])
+            torch.cuda.synchronize()
+            wrong[key] += sum(not torch.equal(a, want[k]) for k in range(2) for a in got[k])
+    total = 2 * reps * trials
+    check("streams/wrong_results_with_one_host_thread_per_stream", wrong["workers"] / total, 0.0, 0.0, "serial launches", absolute=True)
+    check("streams/wrong_results_one_thread_with_backward_turns", wrong["one_thread_with_turns"] / total, 0.0, 0.0, "serial launches", absolute=True)
+    check("streams/wrong_results_one_thread_two_streams_unprotected(recorded_not_asserted)", wrong["one_thread_unprotected"] / total, 0.0, 1.0,
+          "serial launches", absolute=True)
+
+
 def test_captured_gradcam_graphs_replayed_concurrently_on_three_streams(resnet):
     """Grad-CAM as a hipGraph per stream (sweep_images(streams=3) + capture_gradcam): three graphs of the full ResNet-50 forward +
     backward-to-layer4 replay CONCURRENTLY on three streams.  Concurrent replays of captured classifier passes are not a given

@@ -491,9 +491,9 @@ def test_sweep_reference_counter_mode_writes_the_reference_csv_rows(tmp_path):
     model = tiny_from(g, DEV)
     n = int(g["images_used"])
     images = [torch.from_numpy(g["x"][i:i + 1]) for i in range(n)]
+    sal_of = {g["x"][i].tobytes(): g["saliency"][i] for i in range(n)}        # by content: with streams > 1 attr_fn runs on worker threads, in any order
     for streams in (1, 3):
-        calls = iter(range(n))
-        total, used, attr_t = sweep_images(images, model, DEV, lambda x, t: g["saliency"][next(calls)], img_hw=32, batch_size=50,
+        total, used, attr_t = sweep_images(images, model, DEV, lambda x, t: sal_of[x.cpu().numpy().tobytes()], img_hw=32, batch_size=50,
                                            reference_counter=True, streams=streams)
         assert used == n and list(total) == g["csv_keys"].tolist()
         path = tmp_path / f"s{streams}" / "ig_5_images.csv"
@@ -502,8 +502,7 @@ def test_sweep_reference_counter_mode_writes_the_reference_csv_rows(tmp_path):
         assert [r[0] for r in rows] == g["csv_keys"].tolist() + ["Attr Avg Runtime", "Total Runtime"]
         for (k, v), want in zip(rows[:-2], g["csv_values"].tolist()):
             check(f"sweep_reference_counter/{k}", float(v), float(want), 1e-5, absolute=True)
-    calls = iter(range(n))
-    plain, _, _ = sweep_images(images, model, DEV, lambda x, t: g["saliency"][next(calls)], img_hw=32, batch_size=50)
+    plain, _, _ = sweep_images(images, model, DEV, lambda x, t: sal_of[x.cpu().numpy().tobytes()], img_hw=32, batch_size=50)
     assert set(plain) == set(KEYS) and plain["MONO_pos"] < 0 < total["MONO_pos"]          # the default fold keeps the negative history
 
 
@@ -637,8 +636,9 @@ images = [torch.from_numpy(g["x"][i:i + 1]) for i in range(3)]
 sal = {i: g["saliency"][i] for i in range(3)}
 def attr_fn_for(idx_iter):
     return lambda x, t: sal[next(idx_iter)]
-def attr_fn_for_map(maps, idx_iter):
-    return lambda x, t: maps[next(idx_iter)]
+def attr_fn_by_content(xs, maps):
+    table = {xs[i].tobytes(): maps[i] for i in range(len(xs))}        # attr_fn runs on stream worker threads, in any order
+    return lambda x, t: table[x.cpu().numpy().tobytes()]
 total, used, _ = sweep.sweep_images(images, model, dev, attr_fn_for(iter(sweep.shard_indices(3, rank, world))), img_hw=32, rank=rank, world=world)
 one, used1, _ = sweep.sweep_images(images, model, dev, attr_fn_for(iter(range(3))), img_hw=32, rank=0, world=1) if rank == 0 else (None, 3, None)
 assert used == 3
@@ -651,12 +651,12 @@ mc = tiny_from(gc, dev)
 n_img = int(gc["images_used"])
 imgs = [torch.from_numpy(gc["x"][i:i + 1]) for i in range(n_img)]
 sal_c = {i: gc["saliency"][i] for i in range(n_img)}
-tot_c, used_c, secs_c = sweep.sweep_images(imgs, mc, dev, attr_fn_for_map(sal_c, iter(sweep.shard_indices(n_img, rank, world))), img_hw=32, rank=rank, world=world,
+tot_c, used_c, secs_c = sweep.sweep_images(imgs, mc, dev, attr_fn_by_content(gc["x"], sal_c), img_hw=32, rank=rank, world=world,
                                            reference_counter=True, streams=2)
 assert used_c == n_img and list(tot_c) == gc["csv_keys"].tolist(), (list(tot_c), gc["csv_keys"].tolist())
 for k, v in zip(gc["csv_keys"].tolist(), gc["csv_values"].tolist()):
     assert abs(tot_c[k] / n_img - float(v)) <= 1e-5, (k, tot_c[k] / n_img, v)
-alone_c, _, _ = sweep.sweep_images(imgs, mc, dev, attr_fn_for_map(sal_c, iter(range(n_img))), img_hw=32, rank=0, world=1, reference_counter=True)
+alone_c, _, _ = sweep.sweep_images(imgs, mc, dev, attr_fn_by_content(gc["x"], sal_c), img_hw=32, rank=0, world=1, reference_counter=True)
 assert list(alone_c) == list(tot_c) and all(alone_c[k] == tot_c[k] for k in tot_c)          # the same Counter for every world size, bit for bit
 # (2) RISE masks sharded: == single-process rise with the same draw
 x = torch.from_numpy(g["x"][0:1])
