@@ -6,6 +6,8 @@ then torchvision Resize -> x ones(3,H,W) -> |sum over channels| (:153,:181).  Th
 and the backward to the layer stay PyTorch-ROCm; the channel-weighted reduction and the
 up-sample are xai_gradcam_f32 / xai_bilinear_up_f32.
 """
+import threading
+
 import torch
 
 from . import kernels as K
@@ -34,10 +36,11 @@ class LayerGradCam:
 
     def _act_and_grad(self, inputs, target, additional_forward_args=None, layer_input=False):
         kept = {}
+        me = threading.get_ident()       # module hooks are shared by every thread that runs this model: keep only OUR pass's tensor
         if layer_input:                                 # captum's attribute_to_layer_input: the layer's (first) input instead of its output
-            handle = self.layer.register_forward_pre_hook(lambda mod, inp: kept.__setitem__("act", inp[0]))
+            handle = self.layer.register_forward_pre_hook(lambda mod, inp: kept.__setitem__("act", inp[0]) if threading.get_ident() == me else None)
         else:
-            handle = self.layer.register_forward_hook(lambda mod, inp, out: kept.__setitem__("act", out))
+            handle = self.layer.register_forward_hook(lambda mod, inp, out: kept.__setitem__("act", out) if threading.get_ident() == me else None)
         extra = () if additional_forward_args is None else \
             (tuple(additional_forward_args) if isinstance(additional_forward_args, (tuple, list)) else (additional_forward_args,))
         try:
@@ -124,6 +127,9 @@ def _n_classes(model, x):
     return (out if isinstance(out, torch.Tensor) else out.logits).shape[1]
 
 
+_CAPTURE_LOCK = threading.Lock()      # one hipGraph capture at a time in the process: two threads inside capture_end crash the runtime
+
+
 class CapturedGradCam:
     """`gradcam_saliency` for a fixed input shape as ONE hipGraph replay.
 
@@ -146,16 +152,19 @@ class CapturedGradCam:
         self.target = torch.zeros(self.x.shape[0], dtype=torch.int64, device=self.dev)
         self._cam = LayerGradCam(model, layer)
         self._channels = float(channels)
-        side = torch.cuda.Stream(self.dev)
-        side.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):                       # MIOpen picks its algorithms here, never inside the capture
-                self._run()
-        torch.cuda.current_stream(self.dev).wait_stream(side)
-        torch.cuda.synchronize(self.dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.sal = self._run()
+        with _CAPTURE_LOCK:
+            side = torch.cuda.Stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):                       # MIOpen picks its algorithms here, never inside the capture
+                    self._run()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            self.graph = torch.cuda.CUDAGraph()
+            # thread_local: other stream workers keep launching and allocating while this thread captures; the default ("global") lets
+            # any other thread's hipMalloc invalidate the capture
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.sal = self._run()
         if verify:
             self._verify(model, layer, channels)
 
@@ -181,7 +190,8 @@ class CapturedGradCam:
 
     def _act_grad(self):
         kept = {}
-        handle = self._cam.layer.register_forward_hook(lambda mod, inp, out: kept.__setitem__("act", out))
+        me = threading.get_ident()       # (see LayerGradCam._act_and_grad: hooks of other stream workers fire on our forward too)
+        handle = self._cam.layer.register_forward_hook(lambda mod, inp, out: kept.__setitem__("act", out) if threading.get_ident() == me else None)
         try:
             with torch.enable_grad():
                 out = self._cam.forward_func(self.x)

@@ -209,7 +209,8 @@ def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pe
                                      weights=testing_dict.get("weights_path", ""), fold="reference" if reference_counter else "sums")
     total, used, attr_time = _sweep.sweep_images(images, model, dev, attr_fn, img_hw=testing_dict["img_hw"],
                                                  batch_size=testing_dict["batch_size"], fused=fused, rank=rank, world=world,
-                                                 testing_dict=testing_dict, checkpoint=checkpoint, identity=identity, streams=streams,
+                                                 testing_dict=testing_dict, checkpoint=checkpoint, identity=identity,
+                                                 streams=1 if is_vit else streams,      # the hooked ViT keeps per-pass state on its modules
                                                  reference_counter=reference_counter)
     if rank == 0 and used:
         name = f'{testing_dict["attr_func"]}_{testing_dict["image_count"]}_images.csv'

@@ -396,7 +396,9 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     `streams` > 1 (fused flow): consecutive images are queued round-robin on that many HIP streams, each driven by its own host
     thread (xai_engine/streams.py; `attr_fn` and the image access then run on those threads, in no particular order) --
     attribution, ranking and the three step sequences of one image form a serial chain of mostly small or low-occupancy launches,
-    so the chains of `streams` images overlap on the chip.  Every image still runs the same kernels on the same shapes and the per-image Counters are folded
+    so the chains of `streams` images overlap on the chip.  Only for classifiers whose forward keeps no per-pass state ON THE MODEL:
+    the hooked ViT saves attention maps / gradients / block outputs on its modules and TIS / ViT-CX hang hooks on it, so concurrent
+    passes through one such model would read each other's tensors -- use `streams=1` there (the harness does).  Every image still runs the same kernels on the same shapes and the per-image Counters are folded
     in image order, so the sums are bit-identical to `streams=1` (tests/test_gpu_e2e.py::test_sweep_images_on_several_streams).
     The third return value, seconds in attribution, is measured with HIP events on the image's stream when the map stays on the
     device (the reference times a finished attribution, evaluatePerturbation.py:581-590; the host clock around an asynchronous
