@@ -181,7 +181,7 @@ def run_sweep_workload(args, model, dev, rank, world, prep, miopen_mode, fence, 
         for m in methods:
             tdm = dict(td, attr_func=m)
             total, used, _ = sweep_images(imgs, model, dev, lambda x, t, tdm=tdm: get_CNN_attr(x, None, t, tdm), img_hw=H, batch_size=50,
-                                          rank=rank, world=world, streams=args.streams)
+                                          rank=rank, world=world, streams=args.streams, kind=m)
             out[m] = {k: total[k] / max(used, 1) for k in KEYS}
             out[m]["images"] = used
         return out
@@ -219,7 +219,7 @@ def sweep_strong_leg(n_images, model, dev, rank, world, fence, max_over_ranks, s
 
     def one_pass(imgs):
         return sweep_images(imgs, model, dev, lambda x, t: get_CNN_attr(x, None, t, td), img_hw=H, batch_size=50, rank=rank, world=world,
-                            streams=streams)
+                            streams=streams, kind="ig")
 
     one_pass(SyntheticImages(max(2, streams) * world))    # warm-up: one image per stream and rank (solver selection, allocator, workspaces)
     fence()

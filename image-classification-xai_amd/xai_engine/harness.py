@@ -211,7 +211,7 @@ def evaluate_perturbation(testing_dict, rank=0, world=1, fused=True, out_dir="pe
                                                  batch_size=testing_dict["batch_size"], fused=fused, rank=rank, world=world,
                                                  testing_dict=testing_dict, checkpoint=checkpoint, identity=identity,
                                                  streams=1 if is_vit else streams,      # the hooked ViT keeps per-pass state on its modules
-                                                 reference_counter=reference_counter)
+                                                 reference_counter=reference_counter, kind=testing_dict["attr_func"])
     if rank == 0 and used:
         name = f'{testing_dict["attr_func"]}_{testing_dict["image_count"]}_images.csv'
         _sweep.write_csv(os.path.join(out_dir, testing_dict["model_name"], name), total, used, attr_time, time.time() - t_start,

@@ -282,7 +282,8 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
         for lo, hi in spans:
             one_pass(lo, hi)
     else:
-        run_on_streams(dev, n_streams, [lambda lo=lo, hi=hi: one_pass(lo, hi) for lo, hi in spans])
+        kind = ("ig_batch", id(model), images_per_pass, steps, tuple(x.shape[1:]), buffered)
+        run_on_streams(dev, n_streams, [lambda lo=lo, hi=hi: one_pass(lo, hi) for lo, hi in spans], kind=kind)
     if not buffered:
         return K.ig_finish(acc, steps, x, base, want_abs=want_abs)
     n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)

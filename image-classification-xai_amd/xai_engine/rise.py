@@ -92,7 +92,8 @@ def rise(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=N
             job(k, i, j)
     else:
         from .streams import run_on_streams                     # one host thread per stream (streams.py); forward only
-        run_on_streams(dev, n_streams, [lambda k=k, i=i, j=j: job(k, i, j) for k, (i, j) in enumerate(spans)])
+        run_on_streams(dev, n_streams, [lambda k=k, i=i, j=j: job(k, i, j) for k, (i, j) in enumerate(spans)],
+                       kind=("rise", id(model), batch_size, tuple(img.shape)))
     acc = torch.zeros((H, W), dtype=torch.float64, device=dev)
     if n > 0:
         K.rise_accum(g_all, sh_all, scores, cell, H, W, 1.0 / N / p1, acc=acc)

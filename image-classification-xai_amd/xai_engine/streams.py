@@ -49,6 +49,7 @@ class Worker(threading.Thread):
         super().__init__(daemon=True, name=f"xai-stream-{dev.index}-{index}")
         self.dev = dev
         self.stream = None
+        self.warm = set()                               # kinds of work this thread has already run once, alone (see `first_alone`)
         self._q = queue.SimpleQueue()
         self._up = threading.Event()
         self._boot_error = None
@@ -99,11 +100,27 @@ def workers(dev, n):
         return have[:n]
 
 
-def run_on_streams(dev, n, jobs):
+def first_alone(worker, kind, fn):
+    """Run `fn` on `worker`; if the worker has not run this `kind` of work before, run it ALONE: wait until it has been enqueued AND has
+    finished on the device before anything else is handed to any worker by the caller.  Why: the first pass of a kind through a thread's
+    fresh library handles loads (or compiles) every kernel it needs; when three threads do that at the same moment on a box whose caches
+    are cold, some convolutions are served by another (valid, deterministic) solver than in every later call -- measured: a 3-stream
+    sweep started cold differs from its own repetitions by 4e-8 ... 9e-7, a 1-stream sweep started cold does not differ at all
+    (profiles/r03_exp_cold_start_streams.txt).  -> a future."""
+    fut = worker.submit(fn)
+    if kind is not None and kind not in worker.warm:
+        concurrent.futures.wait([fut])
+        worker.stream.synchronize()
+        worker.warm.add(kind)
+    return fut
+
+
+def run_on_streams(dev, n, jobs, kind=None):
     """Run the callables `jobs` round-robin on `n` stream workers (job i on worker i % n) and return their results in order.
     Every job starts after the work the calling thread has queued on its current stream so far; when this returns, the calling
-    thread's current stream waits for everything the jobs queued.  Exceptions of jobs are re-raised here (the first one, after all
-    jobs have been collected -- nothing is left running on a worker)."""
+    thread's current stream waits for everything the jobs queued.  `kind`: a hashable name for what the jobs do (driver, model,
+    shapes); the first job of a kind on each worker runs alone (`first_alone`).  Exceptions of jobs are re-raised here (the first
+    one, after all jobs have been collected -- nothing is left running on a worker)."""
     dev = torch.device(dev)
     main = torch.cuda.current_stream(dev)
     ws = workers(dev, n)
@@ -116,7 +133,7 @@ def run_on_streams(dev, n, jobs):
             return job()
         return run
 
-    futs = [ws[i % n].submit(wrap(job)) for i, job in enumerate(jobs)]
+    futs = [first_alone(ws[i % n], kind, wrap(job)) for i, job in enumerate(jobs)]
     concurrent.futures.wait(futs)
     join(dev, ws, main)
     return [f.result() for f in futs]

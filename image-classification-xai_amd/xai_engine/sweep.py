@@ -377,7 +377,7 @@ class SweepState:
 
 
 def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fused=True, rank=0, world=1, testing_dict=None,
-                 checkpoint=None, checkpoint_every=25, identity=None, streams=1, reference_counter=False):
+                 checkpoint=None, checkpoint_every=25, identity=None, streams=1, reference_counter=False, kind=None):
     """Attribution + ten perturbation numbers for every image this rank owns; returns the
     globally reduced (Counter of sums, images used, seconds in attribution).
     images: sequence of (1,C,H,W) CPU/device tensors (already selected -- the order-dependent
@@ -426,8 +426,11 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     n_streams = max(1, int(streams)) if fused else 1
     ws = None
     if n_streams > 1:
-        from .streams import workers, join
+        from .streams import workers, join, first_alone
         ws = workers(dev, n_streams)                     # one host thread per stream (streams.py)
+        # the first image of a kind of sweep on each worker runs alone (streams.first_alone); `kind` names what attr_fn does (the
+        # harness passes the method name), by default the function object itself
+        kind = ("sweep", id(model), kind if kind is not None else id(attr_fn), img_hw, batch_size)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))     # weights, blur taps: whatever the caller's stream has queued so far
     pending = collections.deque()                        # (future or result, pos) of the images whose device work is in flight
@@ -475,7 +478,7 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
         for pos in range(st.next_pos, len(mine)):
             # `n_streams` images deep: queue this image's device work (on its stream's worker thread), then do the oldest image's
             # host arithmetic while the device runs
-            pending.append((ws[pos % n_streams].submit(lambda pos=pos: device_part(pos)) if ws is not None else device_part(pos), pos))
+            pending.append((first_alone(ws[pos % n_streams], kind, lambda pos=pos: device_part(pos)) if ws is not None else device_part(pos), pos))
             while len(pending) > (n_streams if fused else 0):
                 finish_oldest()
     except BaseException as e:
