@@ -214,7 +214,7 @@ def run_sweep_workload(args, model, dev, rank, world, prep, miopen_mode, fence, 
 def sweep_strong_leg(n_images, model, dev, rank, world, fence, max_over_ranks, streams):
     """Strong-scaling leg of the default line: IG (50 steps) + the ten insertion/deletion numbers of every image of ONE fixed list,
     image i on rank i % world, one all-reduce(SUM) of 12 fp64.  Returns the object for the JSON line (the same on every rank)."""
-    from xai_engine.sweep import sweep_images, get_CNN_attr, KEYS
+    from xai_engine.sweep import sweep_images, get_CNN_attr, KEYS, FORWARD_COUNTS
     td = {"models": [model], "img_hw": H, "batch_size": 50, "device": str(dev), "device_maps": True, "attr_func": "ig"}
 
     def one_pass(imgs):
@@ -231,6 +231,7 @@ def sweep_strong_leg(n_images, model, dev, rank, world, fence, max_over_ranks, s
             "workload": f"insertion/deletion sweep over a fixed list of {n_images} synthetic 3x224x224 images (seeds 1000..): IG 50 steps + ten "
                         "metrics x 224 perturbation steps per image, batch 50 (BASELINE config 5 restricted to one method)",
             "parallelism": f"image i -> rank i % {world}; one all-reduce(SUM) of 12 fp64 (96 B)", "images_used": used,
+            "forward_batches_warmup_and_timed": dict(FORWARD_COUNTS),
             "metric_means": {k: total[k] / max(used, 1) for k in KEYS}}
 
 
@@ -377,7 +378,9 @@ def main():
         step(events)
     fence()
     dt = max_over_ranks(time.perf_counter() - t0)
-    log(f"timed {args.steps} steps in {dt:.3f} s ({world * B * args.steps / dt:.1f} attributions/s)")
+    from xai_engine.ig import PASS_COUNTS
+    how = dict(PASS_COUNTS)
+    log(f"timed {args.steps} steps in {dt:.3f} s ({world * B * args.steps / dt:.1f} attributions/s); classifier passes so far: {how}")
 
     algo_bytes = B * (STEPS_IG + 2) * 4 * N_ELEM + B * H * W * 4      # read S grads + x, write out (+ |sum_c| map); b is a scalar
     # two HIP-event timings of the accumulation launches of the timed steps: events bracketing each launch (they include the
@@ -456,7 +459,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"IG 50 steps, ResNet-50 (seeded random weights), {B}-image batch of 3x224x224 per GPU, "
                                    "alpha_star=1, baseline=0", "images_per_gpu": B, "ig_steps": STEPS_IG, "mode": args.mode,
-                       "images_per_pass": args.images_per_pass, "streams": args.streams, "classifier_prep": prep, "miopen": miopen_mode,
+                       "images_per_pass": args.images_per_pass, "streams": args.streams, "classifier_passes_warmup_and_timed": how,
+                       "classifier_prep": prep, "miopen": miopen_mode,
                        "parallelism": f"image-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "xai_ig_accum_f32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "measured_copy_peak": HBM_COPY_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,

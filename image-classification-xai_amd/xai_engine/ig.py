@@ -7,6 +7,7 @@ shapes, the print-and-return-zeros error convention); `ig_batch` is the multi-im
 path the reference does not have.
 """
 import contextlib
+import threading
 
 import torch
 
@@ -217,8 +218,63 @@ def IDGI(input, model, steps, batch_size, baseline, device, target_class):
     return K.idgi_accum(g, logits[0].contiguous(), K.sumsq(g))
 
 
+_CAPTURE_LOCK = threading.Lock()          # one hipGraph capture at a time in the process (two threads inside capture_end crash the runtime)
+_thread_graphs = threading.local()        # per host thread: {key: _CapturedPass} -- a graph is replayed only by the thread that captured it
+PASS_COUNTS = {"replayed": 0, "eager": 0, "captures": 0, "captures_refused": 0}     # how ig_batch's passes ran (diagnostics; bench.py prints them)
+
+
+class _CapturedPass:
+    """K1 + classifier forward + backward of `k` images x `steps` interpolants as ONE hipGraph on static buffers.
+
+    Why: with one host thread per stream (streams.py) the passes of a step are enqueued by three Python threads that share one
+    interpreter lock -- ~1000 launches and ~100 autograd nodes per pass; the host, not the GPU, becomes the limit (77-84 attributions/s
+    eager against 84-85 replayed, ResNet-50).  A replay is one launch.
+    Why it is safe: a graph bakes in the pointers of the library workspaces its kernels were captured with, and those belong to the
+    capturing THREAD's MIOpen / rocBLAS handles (streams.py).  Each stream worker captures its own graph, on its own handles, with
+    autograd inline, and is the only thread that ever replays it -- graphs of different workers share nothing.  (Graphs captured by ONE
+    thread and replayed on several streams corrupt each other: profiles/r03_exp_ig_graph_streams*.jsonl.)
+    The capture proves itself: its first replay must reproduce the eager pass on the same buffers bit for bit, else the pass stays eager."""
+
+    def __init__(self, model, k, steps, img_shape, dev, alphas, base_tensor, base_scalar):
+        self.x = torch.zeros((k,) + img_shape, dtype=torch.float32, device=dev)
+        self.t = torch.zeros(k, dtype=torch.int64, device=dev)
+        self.base = torch.zeros_like(self.x) if base_tensor else None
+        self.base_scalar, self.alphas, self.model, self.steps, self.img_shape = base_scalar, alphas, model, steps, img_shape
+        cur = torch.cuda.current_stream(dev)
+        for _ in range(2):                                    # MIOpen picks its solvers and loads their kernels here, never inside the capture
+            eager_g, eager_s = self._run()
+        cur.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with _CAPTURE_LOCK:
+            # thread_local: the other stream workers may keep launching and allocating while this thread captures
+            with torch.cuda.graph(self.graph, stream=cur, capture_error_mode="thread_local"):
+                self.g, self.scores = self._run()
+        self.graph.replay()
+        cur.synchronize()
+        self.ok = bool(torch.equal(self.g, eager_g) and torch.equal(self.scores, eager_s))
+        PASS_COUNTS["captures" if self.ok else "captures_refused"] += 1
+        if not self.ok:
+            self.graph = self.g = self.scores = None          # give the graph's memory pool back; the pass stays eager
+
+    def _run(self):
+        imgs = K.ig_interp(self.x, self.base if self.base is not None else self.base_scalar, self.alphas)
+        flat = imgs.view((-1,) + self.img_shape).requires_grad_(True)
+        out = _logits_of(self.model(flat))
+        scores = out.gather(1, self.t.repeat_interleave(self.steps).unsqueeze(1)).squeeze(1)
+        (g,) = torch.autograd.grad(scores, flat, grad_outputs=torch.ones_like(scores))
+        return g.contiguous(), scores.detach()
+
+    def __call__(self, x, targets, base):
+        self.x.copy_(x, non_blocking=True)
+        self.t.copy_(targets, non_blocking=True)
+        if self.base is not None:
+            self.base.copy_(base, non_blocking=True)
+        self.graph.replay()
+        return self.g, self.scores
+
+
 def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_pass=4, want_abs=False,
-             grads_buffer=None, event_sink=None, buffered=None, streams=1):
+             grads_buffer=None, event_sink=None, buffered=None, streams=1, graphs=None):
     """Multi-image IG / Left-IG: x (B,C,H,W) on a HIP device, targets (B,) long.
     `images_per_pass` images x `steps` interpolants go through the classifier at once.
     Returns (B,C,H,W) [and the (B,H,W) |sum_c| map the metrics consume].
@@ -236,6 +292,9 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
     per-handle library workspaces) -- the forward of one pass overlaps the backward of another.  Every pass still launches the
     same kernels on the same shapes and writes disjoint rows, so the result is bit-identical to `streams=1`
     (tests/test_gpu_configs.py::test_classifier_passes_on_several_streams_are_bit_identical_to_one_stream).
+    `graphs` (with `streams` > 1; default on): every stream worker replays its full-size passes as ONE hipGraph it captured itself
+    (`_CapturedPass`: the host stops being the limit once three threads enqueue); a ragged last pass, or a capture whose first replay
+    does not reproduce the eager pass bit for bit, runs eagerly.
     `event_sink`: optional list that receives (start, end, kernel_start, kernel_stop) torch.cuda.Events of the
     accumulation launch: a pair bracketing it and a pair stamped by the dispatch itself (used by bench.py for the roofline figure)."""
     if not x.is_cuda:
@@ -259,15 +318,36 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
         logits = torch.empty((B, steps), dtype=torch.float32, device=dev)
     else:
         acc = torch.zeros_like(x)
-    def one_pass(lo, hi):
+    img_shape = tuple(x.shape[1:])
+    use_graphs = (graphs if graphs is not None else True)
+
+    def captured(k):
+        """this thread's graph of a k-image pass, or None (eager)"""
+        cache = getattr(_thread_graphs, "passes", None)
+        if cache is None:
+            cache = _thread_graphs.passes = {}
+        key = (id(model), k, steps, img_shape, str(dev), torch.is_tensor(base), None if torch.is_tensor(base) else float(base),
+               bool(torch.backends.cudnn.deterministic), bool(torch.backends.cudnn.benchmark))
+        if key not in cache:
+            if len(cache) >= 4:                                                   # a handful of (model, shape) combinations per thread
+                cache.pop(next(iter(cache)))
+            cache[key] = _CapturedPass(model, k, steps, img_shape, dev, alphas, torch.is_tensor(base), None if torch.is_tensor(base) else float(base))
+        return cache[key] if cache[key].ok else None
+
+    def one_pass(lo, hi, on_worker=False):
         b = base[lo:hi] if torch.is_tensor(base) else base
-        imgs = K.ig_interp(x[lo:hi], b, alphas)                                  # (k, steps, C,H,W)
-        flat = imgs.view((-1,) + tuple(x.shape[1:])).requires_grad_(True)
-        out = _logits_of(model(flat))
-        scores = out.gather(1, targets[lo:hi].repeat_interleave(steps).unsqueeze(1)).squeeze(1)
-        with backward_turn(dev):
-            (g,) = torch.autograd.grad(scores, flat, grad_outputs=torch.ones_like(scores))
-        g = g.contiguous()
+        cp = captured(hi - lo) if (on_worker and use_graphs and hi - lo == images_per_pass) else None
+        PASS_COUNTS["replayed" if cp is not None else "eager"] += 1
+        if cp is not None:
+            g, scores = cp(x[lo:hi], targets[lo:hi], b if torch.is_tensor(base) else None)
+        else:
+            imgs = K.ig_interp(x[lo:hi], b, alphas)                              # (k, steps, C,H,W)
+            flat = imgs.view((-1,) + img_shape).requires_grad_(True)
+            out = _logits_of(model(flat))
+            scores = out.gather(1, targets[lo:hi].repeat_interleave(steps).unsqueeze(1)).squeeze(1)
+            with backward_turn(dev):
+                (g,) = torch.autograd.grad(scores, flat, grad_outputs=torch.ones_like(scores))
+            g = g.contiguous()
         if buffered:
             K.store_grads(g, grads_buffer[lo:hi])
             logits[lo:hi] = scores.detach().view(hi - lo, steps)
@@ -282,8 +362,8 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
         for lo, hi in spans:
             one_pass(lo, hi)
     else:
-        kind = ("ig_batch", id(model), images_per_pass, steps, tuple(x.shape[1:]), buffered)
-        run_on_streams(dev, n_streams, [lambda lo=lo, hi=hi: one_pass(lo, hi) for lo, hi in spans], kind=kind)
+        kind = ("ig_batch", id(model), images_per_pass, steps, img_shape, buffered, use_graphs)
+        run_on_streams(dev, n_streams, [lambda lo=lo, hi=hi: one_pass(lo, hi, on_worker=True) for lo, hi in spans], kind=kind)
     if not buffered:
         return K.ig_finish(acc, steps, x, base, want_abs=want_abs)
     n_use = None if alpha_star == 1 else K.ig_cutoff(logits, alpha_star)

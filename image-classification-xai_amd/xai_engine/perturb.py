@@ -26,10 +26,12 @@ class _Probe:
         self.p, self.entropy, self.argmax = K.softmax_stats(logits.float().contiguous(), target, out=out, offset=offset)
 
 
-def sequence_stats(stats, start, finish, flip, n_steps, batches, target, first):
+def sequence_stats(stats, start, finish, flip, n_steps, batches, target, first, slot_for=None):
     """Run one insertion/deletion sequence on the device.  `stats(images, target, out, offset) -> _Probe`
     writes its rows straight into the curves; start/finish (C,H,W); flip (H*W,) int32; `first` = the _Probe
-    of curve point 0.  Returns device tensors p[target], entropy, argmax of length n_steps + 1."""
+    of curve point 0.  Returns device tensors p[target], entropy, argmax of length n_steps + 1.
+    `slot_for(b)`: optional; the static input buffer (b,C,H,W) of a captured forward pass for batches of b images, or None --
+    K6 then writes the step images straight into it (sweep.PerturbationSweep replays the classifier forward as a hipGraph)."""
     dev = start.device
     p = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
     ent = torch.empty(n_steps + 1, dtype=torch.float32, device=dev)
@@ -40,7 +42,8 @@ def sequence_stats(stats, start, finish, flip, n_steps, batches, target, first):
     for b in batches:
         if b == 0:                                      # MonotonicityTest's empty remainder batch: nothing to add
             continue
-        images = K.perturb_batch(start, finish, flip, done, b, out=buf[:b])
+        slot = slot_for(b) if slot_for is not None else None
+        images = K.perturb_batch(start, finish, flip, done, b, out=slot if slot is not None else buf[:b])
         stats(images, target, (p, ent, am), 1 + done)
         done += b
     return p, ent, am

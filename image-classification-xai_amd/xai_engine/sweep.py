@@ -14,6 +14,7 @@ import collections
 import contextlib
 import csv
 import os
+import threading
 import time
 from collections import Counter
 
@@ -160,6 +161,36 @@ def run_perturbation(input_tensor, attribution, testing_dict, CLIP_test_info=Non
                     "MONO_pos": MONO_pos, "MONO_neg": MONO_neg})
 
 
+_CAPTURE_LOCK = threading.Lock()         # one hipGraph capture at a time in the process
+_thread_forwards = threading.local()     # per host thread: {key: _CapturedForward}
+FORWARD_COUNTS = {"replayed": 0, "eager": 0, "captures": 0, "captures_refused": 0}
+
+
+class _CapturedForward:
+    """The classifier's forward pass for a batch of b step images as ONE hipGraph on a static input buffer, captured and replayed by
+    one stream worker only (same reasoning as ig._CapturedPass: with one host thread per stream the ~250 launches of every forward
+    batch are enqueued under one interpreter lock; a replay is one launch, and a graph captured on the worker's own library
+    handles shares nothing with the other workers' graphs).  Its first replay must reproduce the eager forward bit for bit."""
+
+    def __init__(self, model, b, img_shape, dev):
+        self.x = torch.zeros((b,) + tuple(img_shape), dtype=torch.float32, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            for _ in range(2):
+                eager = _logits_of(model(self.x)).detach().clone()
+            cur.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with _CAPTURE_LOCK:
+                with torch.cuda.graph(self.graph, stream=cur, capture_error_mode="thread_local"):
+                    self.logits = _logits_of(model(self.x))
+            self.graph.replay()
+            cur.synchronize()
+        self.ok = bool(torch.equal(self.logits, eager))
+        FORWARD_COUNTS["captures" if self.ok else "captures_refused"] += 1
+        if not self.ok:
+            self.graph = self.logits = None
+
+
 class PerturbationSweep:
     """The same ten numbers from three device-resident sequences (see module docstring)."""
 
@@ -175,6 +206,20 @@ class PerturbationSweep:
     def _stats(self, images, target, out=None, offset=0):
         with torch.no_grad():
             return _Probe(_logits_of(self.model(images)).detach(), target, out, offset)
+
+    def _captured(self, b, img_shape):
+        """this thread's graph of a b-image forward, or None; only on stream workers (`graphs` is set by sweep_images)"""
+        if not getattr(_thread_forwards, "enabled", False):
+            return None
+        cache = getattr(_thread_forwards, "graphs", None)
+        if cache is None:
+            cache = _thread_forwards.graphs = {}
+        key = (id(self.model), b, tuple(img_shape), str(self.dev), bool(torch.backends.cudnn.deterministic), bool(torch.backends.cudnn.benchmark))
+        if key not in cache:
+            if len(cache) >= 6:
+                cache.pop(next(iter(cache)))
+            cache[key] = _CapturedForward(self.model, b, img_shape, self.dev)
+        return cache[key] if cache[key].ok else None
 
     def launch(self, input_tensor, attribution):
         """Queue the whole device part of one image (probes, ranking, three sequences) and an asynchronous
@@ -202,9 +247,24 @@ class PerturbationSweep:
         f_desc = K.flip_steps(rk[0], True, step)
         f_asc = K.flip_steps(rk[0], False, step)
         seg_d, total = K.segment_sums(sal[0], order[0], True, step, n_steps)
-        ins = sequence_stats(self._stats, blurred[0], img[0], f_desc, n_steps, batches, target, pb)
-        dele = sequence_stats(self._stats, img[0], zeros[0], f_desc, n_steps, batches, target, orig)
-        lerf = sequence_stats(self._stats, img[0], zeros[0], f_asc, n_steps, batches, target, orig)
+        img_shape = tuple(img.shape[1:])
+
+        def slot_for(b):
+            cf = self._captured(b, img_shape)
+            return None if cf is None else cf.x
+
+        def stats(images, tgt, out=None, offset=0):
+            cf = self._captured(images.shape[0], img_shape)
+            if cf is None or images.data_ptr() != cf.x.data_ptr():
+                FORWARD_COUNTS["eager"] += 1
+                return self._stats(images, tgt, out, offset)
+            FORWARD_COUNTS["replayed"] += 1
+            cf.graph.replay()                                  # the step images are in cf.x already (K6 wrote them there)
+            return _Probe(cf.logits, tgt, out, offset)
+
+        ins = sequence_stats(stats, blurred[0], img[0], f_desc, n_steps, batches, target, pb, slot_for)
+        dele = sequence_stats(stats, img[0], zeros[0], f_desc, n_steps, batches, target, orig, slot_for)
+        lerf = sequence_stats(stats, img[0], zeros[0], f_asc, n_steps, batches, target, orig, slot_for)
         packed = torch.cat([ins[0], ins[2].float(), dele[0], dele[2].float(), lerf[0], seg_d, total,
                             orig.p, pb.p, pz.p, pb.argmax.float(), pz.argmax.float(), target.float()])
         host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
@@ -377,7 +437,7 @@ class SweepState:
 
 
 def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fused=True, rank=0, world=1, testing_dict=None,
-                 checkpoint=None, checkpoint_every=25, identity=None, streams=1, reference_counter=False, kind=None):
+                 checkpoint=None, checkpoint_every=25, identity=None, streams=1, reference_counter=False, kind=None, graphs=True):
     """Attribution + ten perturbation numbers for every image this rank owns; returns the
     globally reduced (Counter of sums, images used, seconds in attribution).
     images: sequence of (1,C,H,W) CPU/device tensors (already selected -- the order-dependent
@@ -398,7 +458,9 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     attribution, ranking and the three step sequences of one image form a serial chain of mostly small or low-occupancy launches,
     so the chains of `streams` images overlap on the chip.  Only for classifiers whose forward keeps no per-pass state ON THE MODEL:
     the hooked ViT saves attention maps / gradients / block outputs on its modules and TIS / ViT-CX hang hooks on it, so concurrent
-    passes through one such model would read each other's tensors -- use `streams=1` there (the harness does).  Every image still runs the same kernels on the same shapes and the per-image Counters are folded
+    passes through one such model would read each other's tensors -- use `streams=1` there (the harness does).
+    `graphs` (with `streams` > 1): every stream worker replays the forward passes of its step batches as hipGraphs it captured itself
+    (`_CapturedForward`; three threads enqueueing ~250 launches per batch under one interpreter lock are otherwise the limit).  Every image still runs the same kernels on the same shapes and the per-image Counters are folded
     in image order, so the sums are bit-identical to `streams=1` (tests/test_gpu_e2e.py::test_sweep_images_on_several_streams).
     The third return value, seconds in attribution, is measured with HIP events on the image's stream when the map stays on the
     device (the reference times a finished attribution, evaluatePerturbation.py:581-590; the host clock around an asynchronous
@@ -430,7 +492,7 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
         ws = workers(dev, n_streams)                     # one host thread per stream (streams.py)
         # the first image of a kind of sweep on each worker runs alone (streams.first_alone); `kind` names what attr_fn does (the
         # harness passes the method name), by default the function object itself
-        kind = ("sweep", id(model), kind if kind is not None else id(attr_fn), img_hw, batch_size)
+        kind = ("sweep", id(model), kind if kind is not None else id(attr_fn), img_hw, batch_size, bool(graphs))
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))     # weights, blur taps: whatever the caller's stream has queued so far
     pending = collections.deque()                        # (future or result, pos) of the images whose device work is in flight
@@ -442,6 +504,7 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
         x = images[mine[pos]]
         if ws is not None:
             torch.cuda.current_stream(dev).wait_event(ready)
+            _thread_forwards.enabled = graphs
         if fused and not x.is_cuda:
             # one upload through pinned memory, queued behind the previous image's work: a pageable .to(dev) blocks the
             # host until the stream has drained, which would undo the pipelining
