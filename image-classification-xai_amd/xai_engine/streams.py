@@ -2,7 +2,7 @@
 
 Why: one classifier pass at the reference's batch sizes (50 interpolants, 50 step images) is a dependent chain of several
 hundred launches, many of them too small to fill 256 CUs; a second and a third chain on their own streams fill the gaps
-(IG +23 %, the ten-metric sweep +28 % on one MI355X) without changing a kernel, a shape or a summation order.
+(IG +22 %, the ten-metric sweep +29 % on one MI355X) without changing a kernel, a shape or a summation order.
 
 Why not simply `with torch.cuda.stream(s_k):` from one host thread: on PyTorch-ROCm ONE HOST THREAD DRIVING TWO STREAMS IS NOT
 SAFE.  Measured (profiles/r03_exp_bwd_concurrency_variants.jsonl, r03_exp_eager_concurrency_*.jsonl): of the 27 distinct layers of a
