@@ -16,9 +16,9 @@ reported time is the MAX over ranks.
 The headline `value` is measured in the PARITY configuration (`--mode parity`, the default): MIOpen immediate mode with
 deterministic solvers only and ONE image = the reference's 50-interpolant batch per classifier pass (saliencyMethods.py:40-46)
 -- the configuration every parity test runs and the 1e-5 claim is made on; its classifier passes are run-to-run bit-identical.
-Consecutive passes are queued round-robin on `--streams` HIP streams (default 3), one host thread per stream, backward passes taking
-turns (xai_engine/streams.py): the same kernels on the same shapes, so the maps are bit-identical to the one-stream run, while the
-forward of one pass overlaps the backward of another.
+Consecutive passes run side by side on `--streams` HIP streams (default 3), one host thread per stream, each thread replaying its pass
+as a hipGraph it captured on its own library handles (xai_engine/streams.py): the same kernels on the same shapes, so the maps are
+bit-identical to the one-stream run, while the low-occupancy layers of one pass overlap another pass's work.
 `--mode throughput` is the fastest configuration instead (the shipped MIOpen find-db's solvers, which include split-K kernels
 that are not run-to-run reproducible, and 2 images per pass); at N = 1 the default run measures it in a child process and
 reports it as `throughput_mode`.
@@ -474,7 +474,7 @@ def main():
                                      "reference's 50-interpolant batch per classifier pass (saliencyMethods.py:40-46); the maps are bit-identical to "
                                      "the oracle fed the same classifier outputs and within 1e-5 of the oracle / the reference's CPU outputs "
                                      "(tests/test_gpu_configs.py, tests/test_gpu_e2e.py), whatever --streams is (bit-identical to one stream: "
-                                     "tests/test_gpu_e2e.py::test_ig_batch_passes_on_several_streams)") if parity_cfg else
+                                     "tests/test_gpu_configs.py::test_classifier_passes_on_several_streams_are_bit_identical_to_one_stream)") if parity_cfg else
                                     "this run is NOT the parity configuration (see config.mode / config.miopen / config.images_per_pass)"},
         }
         if not args.lean:
