@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--configs", default="1,2,3,4,5,6")
     ap.add_argument("--rise-masks", type=int, default=8000)
     ap.add_argument("--rise-batch", type=int, default=250)
-    ap.add_argument("--sweep-images", type=int, default=4, help="images per rank")
+    ap.add_argument("--sweep-images", type=int, default=12, help="images per rank")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams for RISE's mask batches and the sweep's images (bit-identical to 1)")
     ap.add_argument("--check", type=int, default=1, help="1 = also compare a reduced case with the CPU oracle")
     ap.add_argument("--miopen-db", type=int, default=1, help="1 = MIOpen find mode on the shipped find-db (see xai_engine/prepare.py)")
@@ -139,8 +139,9 @@ def main():
         score = lambda b: torch.softmax(resnet(b), 1)[:, t]       # noqa: E731
         np.random.seed(3)
         masks = draw_masks((224, 224), N, s, p1)
-        xd.rise_sharded(resnet, x, None, dev, N=min(N, 500), s=s, p1=p1, score_fn=score, batch_size=args.rise_batch,
-                        masks=tuple(m[:min(N, 500)] if i < 2 else m for i, m in enumerate(masks)))
+        # warm-up on the same streams: every stream worker meets its first batch here (in find mode that is a find per thread handle)
+        xd.rise_sharded(resnet, x, None, dev, N=min(N, 1000), s=s, p1=p1, score_fn=score, batch_size=args.rise_batch,
+                        masks=tuple(m[:min(N, 1000)] if i < 2 else m for i, m in enumerate(masks)), streams=args.streams)
         sync(dev); t0 = time.perf_counter()
         sal = xd.rise_sharded(resnet, x, None, dev, N=N, s=s, p1=p1, score_fn=score, batch_size=args.rise_batch, masks=masks, streams=args.streams)
         sync(dev); dt = time.perf_counter() - t0
@@ -204,9 +205,9 @@ def main():
 
         def attr_fn(x, target):
             return IG(x, resnet, 50, 50, 1, 0, dev, target).sum(0).abs()      # stays on the device: no drain between images
-        sweep_images(images[:world], resnet, dev, attr_fn, rank=rank, world=world, streams=args.streams)          # warm-up
+        sweep_images(images[:args.streams * world], resnet, dev, attr_fn, rank=rank, world=world, streams=args.streams, kind="ig")   # warm-up: every worker
         sync(dev); t0 = time.perf_counter()
-        total, used, attr_t = sweep_images(images, resnet, dev, attr_fn, rank=rank, world=world, streams=args.streams)
+        total, used, attr_t = sweep_images(images, resnet, dev, attr_fn, rank=rank, world=world, streams=args.streams, kind="ig")
         sync(dev); dt = time.perf_counter() - t0
         extra = {}
         if args.check and rank == 0:

@@ -486,12 +486,12 @@ def test_fuse_bn_relu_is_a_no_op_off_the_gpu():
 
 
 def test_tolerances_are_tied_to_measured_errors():
-    """profiles/r02_parity.json is the ledger conftest.check wrote on an MI355X (tests/parity_report.sh): every comparison of
+    """profiles/r03_parity.json is the ledger conftest.check wrote on an MI355X (tests/parity_report.sh): every comparison of
     the GPU suite with its measured error and the tolerance asserted.  No tolerance may exceed max(the 1e-5 bar, 2 x the largest error measured in its test family):
     a tolerance is a measurement with head-room, not slack."""
     import json
     from conftest import BAR
-    led = json.load(open(os.path.join(ROOT, "profiles", "r02_parity.json")))
+    led = json.load(open(os.path.join(ROOT, "profiles", "r03_parity.json")))
     assert led["meta"]["exitstatus"] == 0 and led["meta"]["deterministic"] is True
     rows = led["comparisons"]
     assert len(rows) >= 300
