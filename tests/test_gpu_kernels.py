@@ -743,6 +743,39 @@ def test_selfcheck_module(K):
     assert len(results) >= 18
 
 
+def test_stream_workers_run_jobs_in_order_on_their_own_streams_and_hand_errors_back(K):
+    """xai_engine.streams: job i runs on worker i % n, i.e. on that worker's host thread and HIP stream, with autograd inline; results
+    come back in job order; the caller's stream waits for the workers; a failing job re-raises in the caller after all jobs are in."""
+    import threading
+    from xai_engine.streams import run_on_streams, workers, backward_turn
+    dev = torch.device(DEV)
+    ws = workers(dev, 3)
+    assert len({w.ident for w in ws}) == 3 and len({w.stream.cuda_stream for w in ws}) == 3
+    src = torch.arange(12, dtype=torch.float32, device=DEV)
+
+    def job(i):
+        me = threading.current_thread()
+        assert me is ws[i % 3] and torch.cuda.current_stream(dev) == me.stream
+        assert torch.is_grad_enabled() and not torch.autograd.is_multithreading_enabled()      # backward nodes run on this thread
+        x = (src[i:i + 1] * 2).requires_grad_(True)
+        with backward_turn(dev):                                                               # a no-op on a worker
+            (g,) = torch.autograd.grad((x * x).sum(), x)
+        return i, g
+    out = run_on_streams(dev, 3, [lambda i=i: job(i) for i in range(12)], kind="test")
+    assert [o[0] for o in out] == list(range(12))
+    got = torch.cat([o[1] for o in out])                       # consumed on the caller's stream: run_on_streams made it wait for the workers
+    np.testing.assert_array_equal(got.cpu().numpy(), 4.0 * np.arange(12, dtype=np.float32))
+    assert torch.autograd.is_multithreading_enabled()          # thread-local: the caller's autograd mode is untouched
+
+    def bad(i):
+        if i == 4:
+            raise ValueError("job 4 failed")
+        return i
+    with pytest.raises(ValueError, match="job 4 failed"):
+        run_on_streams(dev, 3, [lambda i=i: bad(i) for i in range(8)])
+    assert run_on_streams(dev, 2, [lambda: 7]) == [7]          # the workers are still alive afterwards
+
+
 def test_reentrant_from_two_host_threads_on_two_streams(K):
     """include/xai_hip.h: no global mutable state, re-entrant from several host threads on different streams."""
     import threading
