@@ -12,7 +12,10 @@ alternately on two streams, through autograd's engine thread, with autograd run 
 hipGraph replays of such launches inherit it.  The same launches are right every time (0 of 1440) when a device-side event makes
 the second stream wait for the first, or when each stream is driven by ITS OWN host thread.  PyTorch keeps its MIOpen / rocBLAS
 handles -- and with them the libraries' scratch memory -- per host thread, not per stream: two streams fed through one handle can
-run the split-K GEMM at the same time on the same scratch buffer.  In a whole pass the window is ~100 us of ~13 ms, so an
+run the split-K GEMM at the same time on the same scratch buffer.  Root cause confirmed by switching it off
+(profiles/r03_exp_bwd_concurrency_root_cause.txt): with ROCBLAS_STREAM_ORDER_ALLOC=1 (rocBLAS takes its workspace stream-ordered per
+call instead of from the handle's chunk) or MIOPEN_DEBUG_CONV_GEMM=0 (MIOpen stops using its rocBLAS GEMM solvers) the one-thread,
+two-stream form is right 480 times of 480; by default it is wrong 440-459 times of 480.  In a whole pass the window is ~100 us of ~13 ms, so an
 end-to-end comparison against the one-stream result can pass for a long time (the first version of this module did, bit for bit,
 over thousands of passes); that is luck, not safety.  Hence the rule:
 
