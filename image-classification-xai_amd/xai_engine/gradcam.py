@@ -12,7 +12,7 @@ import torch
 
 from . import kernels as K
 from ._lib import XaiHipError
-from .streams import backward_turn
+from .streams import CAPTURE_LOCK, backward_turn
 
 
 def _grad_of_activation(score, act):
@@ -127,9 +127,6 @@ def _n_classes(model, x):
     return (out if isinstance(out, torch.Tensor) else out.logits).shape[1]
 
 
-_CAPTURE_LOCK = threading.Lock()      # one hipGraph capture at a time in the process: two threads inside capture_end crash the runtime
-
-
 class CapturedGradCam:
     """`gradcam_saliency` for a fixed input shape as ONE hipGraph replay.
 
@@ -152,7 +149,7 @@ class CapturedGradCam:
         self.target = torch.zeros(self.x.shape[0], dtype=torch.int64, device=self.dev)
         self._cam = LayerGradCam(model, layer)
         self._channels = float(channels)
-        with _CAPTURE_LOCK:
+        with CAPTURE_LOCK:
             side = torch.cuda.Stream(self.dev)
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):

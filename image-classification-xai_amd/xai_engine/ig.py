@@ -13,7 +13,7 @@ import torch
 
 from . import kernels as K
 from ._lib import XaiHipError
-from .streams import backward_turn, run_on_streams
+from .streams import CAPTURE_LOCK, backward_turn, run_on_streams
 
 
 def hip_device(device):
@@ -218,7 +218,6 @@ def IDGI(input, model, steps, batch_size, baseline, device, target_class):
     return K.idgi_accum(g, logits[0].contiguous(), K.sumsq(g))
 
 
-_CAPTURE_LOCK = threading.Lock()          # one hipGraph capture at a time in the process (two threads inside capture_end crash the runtime)
 _thread_graphs = threading.local()        # per host thread: {key: _CapturedPass} -- a graph is replayed only by the thread that captured it
 PASS_COUNTS = {"replayed": 0, "eager": 0, "captures": 0, "captures_refused": 0}     # how ig_batch's passes ran (diagnostics; bench.py prints them)
 
@@ -245,7 +244,7 @@ class _CapturedPass:
             eager_g, eager_s = self._run()
         cur.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with _CAPTURE_LOCK:
+        with CAPTURE_LOCK:
             # thread_local: the other stream workers may keep launching and allocating while this thread captures
             with torch.cuda.graph(self.graph, stream=cur, capture_error_mode="thread_local"):
                 self.g, self.scores = self._run()

@@ -42,6 +42,7 @@ _WORKERS_LOCK = threading.Lock()
 _TURN = {}               # device index -> _Turn
 _TURN_LOCK = threading.Lock()
 _local = threading.local()
+CAPTURE_LOCK = threading.Lock()     # ONE hipGraph capture at a time in the process, whoever captures: two threads inside capture_end crash the runtime
 
 
 class Worker(threading.Thread):

@@ -11,7 +11,6 @@ compare MASTestFunctions.py:137-185, AICTestFunctions.py:94-123, PosNegPertFunct
 MonotonicityTest.py:93-120): 3 + 3*n_steps classifier passes instead of ~8*(n_steps+3).
 """
 import collections
-import contextlib
 import csv
 import os
 import threading
@@ -29,6 +28,7 @@ from .gradcam import gradcam_saliency, CapturedGradCam
 from .ig import IG, IDG, getGradientsParallel, hip_device, _logits_of
 from .perturb import (AICMetric, MASMetric, MonotonicityMetric, PositiveNegativePerturbation, _Probe, sequence_stats)
 from .smooth import smoothGrad
+from .streams import CAPTURE_LOCK
 
 KEYS = ("MAS_ins", "MAS_del", "RISE_ins", "RISE_del", "AIC_ins", "AIC_del", "LERF_res", "MORF_res", "MONO_pos", "MONO_neg")
 CNN_ATTR_FUNCS = ("grad", "inp_x_grad", "ig", "lig", "idg", "sg", "gc")
@@ -161,7 +161,6 @@ def run_perturbation(input_tensor, attribution, testing_dict, CLIP_test_info=Non
                     "MONO_pos": MONO_pos, "MONO_neg": MONO_neg})
 
 
-_CAPTURE_LOCK = threading.Lock()         # one hipGraph capture at a time in the process
 _thread_forwards = threading.local()     # per host thread: {key: _CapturedForward}
 FORWARD_COUNTS = {"replayed": 0, "eager": 0, "captures": 0, "captures_refused": 0}
 
@@ -180,7 +179,7 @@ class _CapturedForward:
                 eager = _logits_of(model(self.x)).detach().clone()
             cur.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with _CAPTURE_LOCK:
+            with CAPTURE_LOCK:
                 with torch.cuda.graph(self.graph, stream=cur, capture_error_mode="thread_local"):
                     self.logits = _logits_of(model(self.x))
             self.graph.replay()
