@@ -459,8 +459,9 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
     the hooked ViT saves attention maps / gradients / block outputs on its modules and TIS / ViT-CX hang hooks on it, so concurrent
     passes through one such model would read each other's tensors -- use `streams=1` there (the harness does).
     `graphs` (with `streams` > 1): every stream worker replays the forward passes of its step batches as hipGraphs it captured itself
-    (`_CapturedForward`; three threads enqueueing ~250 launches per batch under one interpreter lock are otherwise the limit).  Every image still runs the same kernels on the same shapes and the per-image Counters are folded
-    in image order, so the sums are bit-identical to `streams=1` (tests/test_gpu_e2e.py::test_sweep_images_on_several_streams).
+    (`_CapturedForward`; three threads enqueueing ~250 launches per batch under one interpreter lock are otherwise the limit).
+    Every image still runs the same kernels on the same shapes and the per-image Counters are folded in image order, so the sums are
+    bit-identical to `streams=1` (tests/test_gpu_configs.py::test_classifier_passes_on_several_streams_are_bit_identical_to_one_stream).
     The third return value, seconds in attribution, is measured with HIP events on the image's stream when the map stays on the
     device (the reference times a finished attribution, evaluatePerturbation.py:581-590; the host clock around an asynchronous
     launch would only see the enqueue)."""
