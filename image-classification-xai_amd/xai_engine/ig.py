@@ -13,7 +13,7 @@ import torch
 
 from . import kernels as K
 from ._lib import XaiHipError
-from .streams import CAPTURE_LOCK, backward_turn, run_on_streams
+from .streams import CAPTURE_LOCK, backward_turn, on_worker, run_on_streams
 
 
 def hip_device(device):
@@ -356,7 +356,7 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
                 K.ig_accum_add(g[j], acc[lo + j])
 
     spans = [(lo, min(lo + images_per_pass, B)) for lo in range(0, B, images_per_pass)]
-    n_streams = max(1, min(int(streams), len(spans)))
+    n_streams = 1 if on_worker() else max(1, min(int(streams), len(spans)))      # (called from a stream worker: that thread is the stream)
     if n_streams == 1:
         for lo, hi in spans:
             one_pass(lo, hi)

@@ -72,7 +72,8 @@ def rise(model, image, txt_embedding, device, N=2000, s=8, p1=0.5, *, score_fn=N
     n = hi - lo
     scores = torch.empty(n, dtype=torch.float32, device=dev)
     spans = [(i, min(i + batch_size, n)) for i in range(0, n, batch_size)]
-    n_streams = max(1, min(int(streams), len(spans)))
+    from .streams import on_worker
+    n_streams = 1 if on_worker() else max(1, min(int(streams), len(spans)))
     bufs = [torch.empty((min(batch_size, max(n, 1)),) + tuple(img.shape), dtype=torch.float32, device=dev) for _ in range(n_streams)]
 
     def one_batch(i, j, buf):

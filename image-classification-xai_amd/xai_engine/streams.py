@@ -92,6 +92,11 @@ class Worker(threading.Thread):
         return fut
 
 
+def on_worker():
+    """True on a stream worker's thread."""
+    return isinstance(threading.current_thread(), Worker)
+
+
 def workers(dev, n):
     """The first `n` stream workers of a device (created on first use, kept for the life of the process)."""
     dev = torch.device(dev)
@@ -125,6 +130,8 @@ def run_on_streams(dev, n, jobs, kind=None):
     thread's current stream waits for everything the jobs queued.  `kind`: a hashable name for what the jobs do (driver, model,
     shapes); the first job of a kind on each worker runs alone (`first_alone`).  Exceptions of jobs are re-raised here (the first
     one, after all jobs have been collected -- nothing is left running on a worker)."""
+    if on_worker():            # nested use (a sweep's attr_fn calling ig_batch): this thread IS a stream; its jobs run on it, in order
+        return [job() for job in jobs]
     dev = torch.device(dev)
     main = torch.cuda.current_stream(dev)
     ws = workers(dev, n)

@@ -485,7 +485,8 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
         if checkpoint and (st.next_pos % checkpoint_every == 0 or st.next_pos == len(mine)):
             st.save(checkpoint)
 
-    n_streams = max(1, int(streams)) if fused else 1
+    from .streams import on_worker
+    n_streams = max(1, int(streams)) if (fused and not on_worker()) else 1      # (called from a stream worker: this thread is the stream)
     ws = None
     if n_streams > 1:
         from .streams import workers, join, first_alone

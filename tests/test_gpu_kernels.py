@@ -774,6 +774,9 @@ def test_stream_workers_run_jobs_in_order_on_their_own_streams_and_hand_errors_b
     with pytest.raises(ValueError, match="job 4 failed"):
         run_on_streams(dev, 3, [lambda i=i: bad(i) for i in range(8)])
     assert run_on_streams(dev, 2, [lambda: 7]) == [7]          # the workers are still alive afterwards
+    # nested use (an attribution that itself fans out, called from a worker): runs on the calling worker, no dead-lock
+    nested = run_on_streams(dev, 2, [lambda: run_on_streams(dev, 3, [lambda j=j: (j, threading.current_thread().name) for j in range(4)])])
+    assert [j for j, _ in nested[0]] == [0, 1, 2, 3] and len({name for _, name in nested[0]}) == 1
 
 
 def test_reentrant_from_two_host_threads_on_two_streams(K):
