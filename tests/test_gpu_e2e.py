@@ -481,6 +481,13 @@ def test_get_CNN_attr_dispatch():
         np.testing.assert_array_equal(devm.cpu().numpy(), host)
     with pytest.raises(SystemExit):
         get_CNN_attr(x, None, t, dict(td, attr_func="nope"))
+    # an attribution that fans out itself (smoothGrad -> ig_batch(streams=3)) inside a multi-stream sweep: the inner fan-out runs on the
+    # calling stream worker (no dead-lock: a worker cannot wait for work queued behind itself)
+    from xai_engine.sweep import sweep_images, KEYS
+    imgs = [torch.randn(1, 3, 32, 32, generator=torch.Generator().manual_seed(70 + i)) for i in range(4)]
+    tds = dict(td, attr_func="sg", device_maps=True)
+    tot, used, _ = sweep_images(imgs, model, DEV, lambda xx, tt: get_CNN_attr(xx, None, tt, tds), img_hw=32, batch_size=25, streams=3)
+    assert used == 4 and all(np.isfinite(tot[k]) for k in KEYS)
 
 
 def test_sweep_reference_counter_mode_writes_the_reference_csv_rows(tmp_path):
