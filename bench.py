@@ -263,6 +263,7 @@ def throughput_child(args):
         d = json.loads(lines[-1])
         return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                 "images_per_pass": d["config"]["images_per_pass"], "streams": d["config"]["streams"], "miopen": d["config"]["miopen"],
+                "classifier_passes_warmup_and_timed": d["config"].get("classifier_passes_warmup_and_timed"),
                 "k2_avg_launch_ms": d["roofline"]["avg_launch_ms"], "k2_frac_of_hbm_peak": d["roofline"]["frac"],
                 "note": "same step, same work, fp32: MIOpen's find-db solvers (they include split-K kernels that are not run-to-run "
                         "reproducible: IG twice differs by ~5e-4, profiles/r02_resnet_determinism_finddb.json) and 2 images = 100 interpolants "

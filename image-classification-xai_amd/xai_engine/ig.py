@@ -232,7 +232,8 @@ class _CapturedPass:
     capturing THREAD's MIOpen / rocBLAS handles (streams.py).  Each stream worker captures its own graph, on its own handles, with
     autograd inline, and is the only thread that ever replays it -- graphs of different workers share nothing.  (Graphs captured by ONE
     thread and replayed on several streams corrupt each other: profiles/r03_exp_ig_graph_streams*.jsonl.)
-    The capture proves itself: its first replay must reproduce the eager pass on the same buffers bit for bit, else the pass stays eager."""
+    The capture proves itself: its first replay must reproduce the eager pass on the same buffers -- bit for bit with deterministic
+    solvers, to the solvers' own run-to-run noise otherwise -- else the pass stays eager."""
 
     def __init__(self, model, k, steps, img_shape, dev, alphas, base_tensor, base_scalar):
         self.x = torch.zeros((k,) + img_shape, dtype=torch.float32, device=dev)
@@ -250,7 +251,10 @@ class _CapturedPass:
                 self.g, self.scores = self._run()
         self.graph.replay()
         cur.synchronize()
-        self.ok = bool(torch.equal(self.g, eager_g) and torch.equal(self.scores, eager_s))
+        if torch.backends.cudnn.deterministic:
+            self.ok = bool(torch.equal(self.g, eager_g) and torch.equal(self.scores, eager_s))
+        else:       # MIOpen's non-deterministic solvers differ run to run by themselves (~1e-3 after ReLU-gate flips); a broken replay is off by tens of per cent
+            self.ok = bool((self.g - eager_g).abs().max() <= 2e-2 * eager_g.abs().max() and (self.scores - eager_s).abs().max() <= 1e-3 * eager_s.abs().max())
         PASS_COUNTS["captures" if self.ok else "captures_refused"] += 1
         if not self.ok:
             self.graph = self.g = self.scores = None          # give the graph's memory pool back; the pass stays eager
@@ -286,10 +290,10 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
                  HBM traffic.
     `buffered`: None = buffered exactly when it has to be (alpha_star != 1) or the caller asked for it by passing
     `grads_buffer` / `event_sink`.
-    `streams` > 1: consecutive classifier passes are queued round-robin on that many HIP streams, each driven by its own host
-    thread, and their backward passes take turns (xai_engine/streams.py: the two rules that make this safe with PyTorch-ROCm's
-    per-handle library workspaces) -- the forward of one pass overlaps the backward of another.  Every pass still launches the
-    same kernels on the same shapes and writes disjoint rows, so the result is bit-identical to `streams=1`
+    `streams` > 1: consecutive classifier passes run side by side on that many HIP streams, each driven by its own host thread with
+    autograd inline (xai_engine/streams.py: why one thread must not feed two streams on PyTorch-ROCm) -- the low-occupancy layers
+    of one pass overlap another pass's work.  Every pass still launches the same kernels on the same shapes and writes disjoint
+    rows, so the result is bit-identical to `streams=1`
     (tests/test_gpu_configs.py::test_classifier_passes_on_several_streams_are_bit_identical_to_one_stream).
     `graphs` (with `streams` > 1; default on): every stream worker replays its full-size passes as ONE hipGraph it captured itself
     (`_CapturedPass`: the host stops being the limit once three threads enqueue); a ragged last pass, or a capture whose first replay

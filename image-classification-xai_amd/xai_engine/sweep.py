@@ -169,7 +169,8 @@ class _CapturedForward:
     """The classifier's forward pass for a batch of b step images as ONE hipGraph on a static input buffer, captured and replayed by
     one stream worker only (same reasoning as ig._CapturedPass: with one host thread per stream the ~250 launches of every forward
     batch are enqueued under one interpreter lock; a replay is one launch, and a graph captured on the worker's own library
-    handles shares nothing with the other workers' graphs).  Its first replay must reproduce the eager forward bit for bit."""
+    handles shares nothing with the other workers' graphs).  Its first replay must reproduce the eager forward (bit for bit with
+    deterministic solvers)."""
 
     def __init__(self, model, b, img_shape, dev):
         self.x = torch.zeros((b,) + tuple(img_shape), dtype=torch.float32, device=dev)
@@ -184,7 +185,10 @@ class _CapturedForward:
                     self.logits = _logits_of(model(self.x))
             self.graph.replay()
             cur.synchronize()
-        self.ok = bool(torch.equal(self.logits, eager))
+        if torch.backends.cudnn.deterministic:
+            self.ok = bool(torch.equal(self.logits, eager))
+        else:                                                  # non-deterministic solvers: to their own run-to-run noise
+            self.ok = bool((self.logits - eager).abs().max() <= 1e-3 * eager.abs().max())
         FORWARD_COUNTS["captures" if self.ok else "captures_refused"] += 1
         if not self.ok:
             self.graph = self.logits = None
