@@ -180,12 +180,18 @@ class _CapturedForward:
                 eager = _logits_of(model(self.x)).detach().clone()
             cur.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with CAPTURE_LOCK:
-                with torch.cuda.graph(self.graph, stream=cur, capture_error_mode="thread_local"):
-                    self.logits = _logits_of(model(self.x))
-            self.graph.replay()
-            cur.synchronize()
-        if torch.backends.cudnn.deterministic:
+            self.logits = None
+            try:
+                with CAPTURE_LOCK:
+                    with torch.cuda.graph(self.graph, stream=cur, capture_error_mode="thread_local"):
+                        self.logits = _logits_of(model(self.x))
+                self.graph.replay()
+                cur.synchronize()
+            except Exception:                                  # a classifier whose forward cannot be captured: eager
+                self.logits = None
+        if self.logits is None:
+            self.ok = False
+        elif torch.backends.cudnn.deterministic:
             self.ok = bool(torch.equal(self.logits, eager))
         else:                                                  # non-deterministic solvers: to their own run-to-run noise
             self.ok = bool((self.logits - eager).abs().max() <= 1e-3 * eager.abs().max())

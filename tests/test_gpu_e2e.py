@@ -126,6 +126,43 @@ def test_IG_streams_when_alpha_star_is_1_and_equals_the_buffered_flow_bit_for_bi
         ig_batch(xs5, model, ts, steps=50, alpha_star=.9, buffered=False)
 
 
+def test_ig_batch_on_stream_workers_with_and_without_graphs_and_with_an_uncapturable_classifier():
+    """ig_batch(streams=3): every worker replays its passes as its own hipGraph when the classifier can be captured, and runs them eagerly
+    when it cannot (a forward with a host sync) or when graphs are switched off -- the same bits as one stream in all three cases."""
+    from xai_engine import ig as igmod
+    from xai_engine.ig import ig_batch
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    xs = torch.randn(7, 3, 32, 32, generator=torch.Generator().manual_seed(9)).to(DEV)
+    with torch.no_grad():
+        ts = model(xs).argmax(1)
+    one = ig_batch(xs, model, ts, steps=50, images_per_pass=2)
+    before = dict(igmod.PASS_COUNTS)
+    with_graphs = ig_batch(xs, model, ts, steps=50, images_per_pass=2, streams=3)
+    after = dict(igmod.PASS_COUNTS)
+    assert after["replayed"] - before["replayed"] == 3 and after["eager"] - before["eager"] == 1       # 3 full passes of 2 images, 1 ragged pass of 1
+    np.testing.assert_array_equal(with_graphs.cpu().numpy(), one.cpu().numpy())
+    no_graphs = ig_batch(xs, model, ts, steps=50, images_per_pass=2, streams=3, graphs=False)
+    np.testing.assert_array_equal(no_graphs.cpu().numpy(), one.cpu().numpy())
+
+    class Syncing(torch.nn.Module):                      # a forward that waits for the device: illegal inside a stream capture
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, x):
+            assert float(x.detach().sum()) == float(x.detach().sum())
+            return self.inner(x)
+    sync_model = Syncing(model)
+    before = dict(igmod.PASS_COUNTS)
+    got = ig_batch(xs, sync_model, ts, steps=50, images_per_pass=2, streams=3)
+    after = dict(igmod.PASS_COUNTS)
+    assert after["captures_refused"] > before["captures_refused"] and after["replayed"] == before["replayed"]
+    np.testing.assert_array_equal(got.cpu().numpy(), one.cpu().numpy())
+    again = ig_batch(xs, model, ts, steps=50, images_per_pass=2, streams=3)            # the workers and their streams are fine afterwards
+    np.testing.assert_array_equal(again.cpu().numpy(), one.cpu().numpy())
+
+
 def test_IDG_IDGI_and_helpers(attr):
     from oracle import ig as oig
     g = load_golden("ig_small.npz")
