@@ -443,6 +443,7 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             traffic_source = ("profiles/ig_accum_pmc.json: FETCH_SIZE/WRITE_SIZE of this kernel at this shape from a separate "
                               "rocprofv3 --pmc run (PMC passes cannot share a process with the timed run); NOT measured in this process")
+        peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30         # everything this rank held at once, graphs' private pools included
         parity_cfg = bool(args.deterministic) and args.images_per_pass == 1 and not tuned and not args.miopen_find
         value = world * B * args.steps / dt
         line = {
@@ -461,7 +462,7 @@ def main():
             "config": {"workload": f"IG 50 steps, ResNet-50 (seeded random weights), {B}-image batch of 3x224x224 per GPU, "
                                    "alpha_star=1, baseline=0", "images_per_gpu": B, "ig_steps": STEPS_IG, "mode": args.mode,
                        "images_per_pass": args.images_per_pass, "streams": args.streams, "classifier_passes_warmup_and_timed": how,
-                       "classifier_prep": prep, "miopen": miopen_mode,
+                       "classifier_prep": prep, "miopen": miopen_mode, "peak_device_memory_gib_rank0": round(peak_gb, 2),
                        "parallelism": f"image-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "xai_ig_accum_f32", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "measured_copy_peak": HBM_COPY_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,

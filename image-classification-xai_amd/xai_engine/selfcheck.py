@@ -120,7 +120,60 @@ def run(device="cuda:0", verbose=True):
     check("maxpool_bwd (bitwise vs PyTorch)", float((K.maxpool_bwd(gp, ip, 15, 17, 3, 2, 1) != xp.grad).sum()), 0.0)
     want = F.max_pool2d(F.relu(F.batch_norm(xb_, mv, vv, wv, bv, False, 0.0, 1e-5)), 3, 2, 1)
     check("bn_relu_maxpool_fwd (bitwise vs PyTorch)", float((K.bn_relu_maxpool_fwd(xb_, wv, bv, mv, vv, 1e-5, BN_VARIANT, 3, 2, 1) != want).sum()), 0.0)
+    # K16 and the stream workers
+    rows, wts = rnd(37, 200).abs(), rnd(37)
+    wsum, psum = K.masked_sums(rows, wts)
+    check("masked_sums", max(_rel(wsum, (rows.double() * wts.double()[:, None]).sum(0) / 37), _rel(psum, rows.double().sum(0) / 37)), 2e-6)
+    wrong = unprotected = 0.0
+    for _ in range(3):          # which solver MIOpen serves the probe's shape with settles after its first uses in a process: look more than once
+        w, u = streams_probe(dev)
+        wrong, unprotected = max(wrong, w), max(unprotected, u)
+    check("stream workers (wrong results)", float(wrong), 0.0)
+    if verbose:
+        print(f"info  one host thread on two streams, unprotected: {unprotected:.0%} of the probe's launches wrong on this stack "
+              "(why xai_engine.streams uses one host thread per stream)")
     return all(r[3] for r in results), results
+
+
+def streams_probe(dev, trials=6, reps=6):
+    """The launch that exposes the one-thread-two-streams hazard of PyTorch-ROCm (xai_engine/streams.py): the backward-data of a 1x1
+    convolution 512 -> 2048 on 7x7 at batch 50 (ResNet-50's layer4.0.conv3).  -> (fraction of wrong results when two stream workers
+    issue it concurrently -- must be 0 --, fraction when one host thread issues it alternately on two streams -- informational)."""
+    from .streams import workers
+    keep = (torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic)
+    # the configuration in which MIOpen serves this launch with its rocBLAS split-K GEMM solver (the parity configuration of the tests)
+    torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
+    conv = torch.nn.Conv2d(512, 2048, 1, bias=False).to(dev)
+    torch.nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+    conv.weight.requires_grad_(False)
+    gen = torch.Generator(device=dev).manual_seed(5)
+
+    def grad(x, gy):
+        xr = x.detach().requires_grad_(True)
+        (gx,) = torch.autograd.grad(conv(xr), xr, gy)
+        return gx
+    ws = workers(dev, 2)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    bad_workers = bad_one_thread = 0
+    for _ in range(trials):
+        xs = [torch.randn(50, 512, 7, 7, device=dev, generator=gen) for _ in range(2)]
+        gys = [torch.randn(50, 2048, 7, 7, device=dev, generator=gen) for _ in range(2)]
+        want = [grad(xs[k], gys[k]) for k in range(2)]
+        torch.cuda.synchronize(dev)
+        got = [f.result() for f in [ws[k].submit(lambda k=k: [grad(xs[k], gys[k]) for _ in range(reps)]) for k in range(2)]]
+        torch.cuda.synchronize(dev)
+        bad_workers += sum(not torch.equal(a, want[k]) for k in range(2) for a in got[k])
+        got = [[], []]
+        for _ in range(reps):
+            for k in range(2):
+                with torch.cuda.stream(streams[k]):
+                    got[k].append(torch.ops.aten.convolution_backward(gys[k], xs[k], conv.weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                                      [True, False, False])[0])
+        torch.cuda.synchronize(dev)
+        bad_one_thread += sum(not torch.equal(a, want[k]) for k in range(2) for a in got[k])
+    total = 2 * reps * trials
+    torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = keep
+    return bad_workers / total, bad_one_thread / total
 
 
 def main(argv=None):
