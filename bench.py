@@ -410,7 +410,8 @@ def main():
             return [IG(x[i:i + 1], model, STEPS_IG, 50, 1, 0, dev, targets[i]) for i in range(B)]
 
         def api_streams():                              # one host thread per stream (xai_engine/streams.py); IG's backward passes take turns
-            return run_on_streams(dev, args.streams, [lambda i=i: IG(x[i:i + 1], model, STEPS_IG, 50, 1, 0, dev, targets[i]) for i in range(B)])
+            return run_on_streams(dev, args.streams, [lambda i=i: IG(x[i:i + 1], model, STEPS_IG, 50, 1, 0, dev, targets[i]) for i in range(B)],
+                                  kind="IG one image")
 
         api_serial()
         da = timed(api_serial, 1)

@@ -112,6 +112,25 @@ def _path(x, base, alphas, model, batch_size, target_class, want_grads=True):
     return grads, logits
 
 
+def _worker_pass(x, base, alphas, model, batch_size, target_class):
+    """On a stream worker, when ONE classifier pass covers the whole path (batch_size == steps): this thread's hipGraph of that pass
+    (`_CapturedPass`, shared with ig_batch) -> (gradients (steps, C,H,W), logits (steps,)), else None.  Same kernels, same bits."""
+    steps = alphas.shape[0]
+    if not on_worker() or batch_size != steps or x.shape[0] != 1:
+        return None
+    if torch.is_tensor(target_class):
+        if not target_class.is_cuda:
+            return None                                    # a host index would need an upload (a host sync on this stream): stay eager
+        t = target_class.reshape(1).long()
+    else:
+        t = torch.full((1,), int(target_class), dtype=torch.int64, device=x.device)
+    cp = _thread_pass(model, 1, steps, tuple(x.shape[1:]), x.device, alphas, base)
+    if cp is None:
+        return None
+    PASS_COUNTS["replayed"] += 1
+    return cp(x, t, base if torch.is_tensor(base) else None)
+
+
 def _path_sum(x, base, alphas, model, batch_size, target_class):
     """Walk the path like `_path`, but keep only the running sum of the step gradients: each pass's autograd gradient
     (cache-resident, `batch_size` x N) is added straight into a (1,C,H,W) fp32 accumulator by the streaming form of K2.
@@ -120,6 +139,10 @@ def _path_sum(x, base, alphas, model, batch_size, target_class):
     (tests/test_gpu_kernels.py::test_ig_streaming_form_equals_buffered, test_IG_streams_when_alpha_star_is_1)."""
     steps = alphas.shape[0]
     acc = torch.zeros_like(x)
+    replay = _worker_pass(x, base, alphas, model, batch_size, target_class)
+    if replay is not None:
+        K.ig_accum_add(replay[0], acc[0])
+        return acc
     for lo in range(0, steps, batch_size):
         imgs = K.ig_interp(x, base, alphas[lo:lo + batch_size])[0].requires_grad_(True)
         g, _ = getGradientsParallel(imgs, model, target_class)
@@ -281,6 +304,20 @@ class _CapturedPass:
         return self.g, self.scores
 
 
+def _thread_pass(model, k, steps, img_shape, dev, alphas, base):
+    """This stream worker's graph of a k-image pass (captured on first use), or None when the pass has to stay eager."""
+    cache = getattr(_thread_graphs, "passes", None)
+    if cache is None:
+        cache = _thread_graphs.passes = {}
+    key = (id(model), k, steps, img_shape, str(dev), torch.is_tensor(base), None if torch.is_tensor(base) else float(base),
+           bool(torch.backends.cudnn.deterministic), bool(torch.backends.cudnn.benchmark))
+    if key not in cache:
+        if len(cache) >= 4:                                                       # a handful of (model, shape) combinations per thread
+            cache.pop(next(iter(cache)))
+        cache[key] = _CapturedPass(model, k, steps, img_shape, dev, alphas, torch.is_tensor(base), None if torch.is_tensor(base) else float(base))
+    return cache[key] if cache[key].ok else None
+
+
 def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_pass=4, want_abs=False,
              grads_buffer=None, event_sink=None, buffered=None, streams=1, graphs=None):
     """Multi-image IG / Left-IG: x (B,C,H,W) on a HIP device, targets (B,) long.
@@ -329,22 +366,9 @@ def ig_batch(x, model, targets, steps=50, alpha_star=1, baseline=0, images_per_p
     img_shape = tuple(x.shape[1:])
     use_graphs = (graphs if graphs is not None else True)
 
-    def captured(k):
-        """this thread's graph of a k-image pass, or None (eager)"""
-        cache = getattr(_thread_graphs, "passes", None)
-        if cache is None:
-            cache = _thread_graphs.passes = {}
-        key = (id(model), k, steps, img_shape, str(dev), torch.is_tensor(base), None if torch.is_tensor(base) else float(base),
-               bool(torch.backends.cudnn.deterministic), bool(torch.backends.cudnn.benchmark))
-        if key not in cache:
-            if len(cache) >= 4:                                                   # a handful of (model, shape) combinations per thread
-                cache.pop(next(iter(cache)))
-            cache[key] = _CapturedPass(model, k, steps, img_shape, dev, alphas, torch.is_tensor(base), None if torch.is_tensor(base) else float(base))
-        return cache[key] if cache[key].ok else None
-
     def one_pass(lo, hi, on_worker=False):
         b = base[lo:hi] if torch.is_tensor(base) else base
-        cp = captured(hi - lo) if (on_worker and use_graphs and hi - lo == images_per_pass) else None
+        cp = _thread_pass(model, hi - lo, steps, img_shape, dev, alphas, base) if (on_worker and use_graphs and hi - lo == images_per_pass) else None
         PASS_COUNTS["replayed" if cp is not None else "eager"] += 1
         if cp is not None:
             g, scores = cp(x[lo:hi], targets[lo:hi], b if torch.is_tensor(base) else None)

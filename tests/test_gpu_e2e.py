@@ -161,6 +161,16 @@ def test_ig_batch_on_stream_workers_with_and_without_graphs_and_with_an_uncaptur
     np.testing.assert_array_equal(got.cpu().numpy(), one.cpu().numpy())
     again = ig_batch(xs, model, ts, steps=50, images_per_pass=2, streams=3)            # the workers and their streams are fine afterwards
     np.testing.assert_array_equal(again.cpu().numpy(), one.cpu().numpy())
+    # the one-image signature issued from stream workers replays the worker's graph of a one-image pass too (batch_size == steps)
+    from xai_engine.streams import run_on_streams
+    from xai_engine.ig import IG
+    before = dict(igmod.PASS_COUNTS)
+    maps = run_on_streams(DEV, 3, [lambda i=i: IG(xs[i:i + 1], model, 50, 50, 1, 0, DEV, ts[i]) for i in range(7)], kind="IG test")
+    assert igmod.PASS_COUNTS["replayed"] - before["replayed"] == 7
+    serial = [IG(xs[i:i + 1], model, 50, 50, 1, 0, DEV, ts[i]) for i in range(7)]
+    for a, b in zip(maps, serial):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    np.testing.assert_array_equal(torch.stack(maps).cpu().numpy(), ig_batch(xs, model, ts, steps=50, images_per_pass=1).cpu().numpy())
 
 
 def test_IDG_IDGI_and_helpers(attr):
