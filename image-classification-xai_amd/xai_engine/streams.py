@@ -112,10 +112,13 @@ def workers(dev, n):
 def first_alone(worker, kind, fn):
     """Run `fn` on `worker`; if the worker has not run this `kind` of work before, run it ALONE: wait until it has been enqueued AND has
     finished on the device before anything else is handed to any worker by the caller.  Why: the first pass of a kind through a thread's
-    fresh library handles loads (or compiles) every kernel it needs; when three threads do that at the same moment on a box whose caches
-    are cold, some convolutions are served by another (valid, deterministic) solver than in every later call -- measured: a 3-stream
-    sweep started cold differs from its own repetitions by 4e-8 ... 9e-7, a 1-stream sweep started cold does not differ at all
-    (profiles/r03_exp_cold_start_streams.txt).  -> a future."""
+    fresh library handles is where MIOpen settles, PER HANDLE, which solver serves which shape; when three threads do that at the same
+    moment on a box whose caches are cold, one of them can settle on another (valid, deterministic) solver for a layer and keeps it for
+    the life of its handle -- measured: of three workers started together, one computed `layer4.1.conv2` (batch 1) differently from the
+    other two and from the main thread in its first AND every later call (profiles/r03_exp_cold_start_which_layer_fused_batch1.jsonl);
+    end to end a 3-stream sweep started that way differs from its own repetitions by 4e-8 ... 9e-7, a 1-stream sweep started cold does
+    not differ at all (profiles/r03_exp_cold_start_streams.txt).  Started one after the other, fresh handles settle like the main
+    thread's.  -> a future."""
     fut = worker.submit(fn)
     if kind is not None and kind not in worker.warm:
         concurrent.futures.wait([fut])
