@@ -579,9 +579,9 @@ def sweep_images(images, model, device, attr_fn, img_hw=224, batch_size=50, fuse
 
 def write_csv(path, counter_sum, images_used, attr_time, total_time, reference_counter=False):
     """rows `key,mean` for the metrics + the two runtime rows (reference :606-618).
-    Default: always the ten keys in KEYS order, plain sums / images.  `reference_counter=True`: `counter_sum` is the Counter of
-    `sweep_images(..., reference_counter=True)` and the loop is the reference's (:612-615) -- only the keys that survived its
-    `+=`, in the Counter's own order."""
+    Default: always the ten keys in KEYS order, plain sums / images, and a last row `Fold,plain sums` that says so.
+    `reference_counter=True`: `counter_sum` is the Counter of `sweep_images(..., reference_counter=True)` and the file is the reference's,
+    row for row (:612-618) -- only the keys that survived its `+=`, in the Counter's own order, then the two runtime rows."""
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     with open(path, "w") as f:
         w = csv.writer(f)
@@ -589,3 +589,5 @@ def write_csv(path, counter_sum, images_used, attr_time, total_time, reference_c
             w.writerow([k, str(counter_sum[k] / images_used)])
         w.writerow(["Attr Avg Runtime", str(attr_time / images_used)])
         w.writerow(["Total Runtime", str(total_time)])
+        if not reference_counter:                        # (nothing in the reference reads these files back; the row tells the two folds apart)
+            w.writerow(["Fold", "plain sums"])

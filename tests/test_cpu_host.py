@@ -397,6 +397,8 @@ def test_reference_counter_fold_and_csv_reproduce_the_reference_rows(tmp_path):
     plain = {k: float(sum(g[f"counter_{i}"][j] for i in range(n))) for j, k in enumerate(sweep.KEYS)}
     sweep.write_csv(str(path), plain, n, 2.5, 10.0)
     rows = [r.split(",") for r in open(path).read().strip().splitlines()]
+    assert rows[-1] == ["Fold", "plain sums"]                          # the default file says which fold it holds; the reference-mode file is the reference's
+    rows = rows[:-1]
     assert [r[0] for r in rows[:-2]] == list(sweep.KEYS)
     assert float(rows[8][1]) < 0 < float(dict(g["csv_keys"].tolist() and zip(g["csv_keys"].tolist(), g["csv_values"].tolist()))["MONO_pos"])
     assert sweep.replay_reference_counter([]) == {}

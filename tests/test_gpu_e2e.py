@@ -575,7 +575,7 @@ def test_sweep_images_single_rank_and_csv(tmp_path):
     path = tmp_path / "pert_test_results" / "T" / "ig_3_images.csv"
     write_csv(str(path), total, used, attr_t, 1.0)
     rows = [r.split(",") for r in open(path).read().strip().splitlines()]
-    assert [r[0] for r in rows] == list(KEYS) + ["Attr Avg Runtime", "Total Runtime"]
+    assert [r[0] for r in rows] == list(KEYS) + ["Attr Avg Runtime", "Total Runtime", "Fold"] and rows[-1][1] == "plain sums"
     assert abs(float(rows[0][1]) - total["MAS_ins"] / 3) < 1e-12
 
 
@@ -666,7 +666,7 @@ def test_evaluate_perturbation_on_a_directory(tmp_path):
     for k in KEYS:
         assert abs(total[k] - want[k]) <= 1e-9, k
     rows = open(tmp_path / "pert_test_results" / "T" / "ig_4_images.csv").read().strip().splitlines()
-    assert len(rows) == 12 and rows[0].startswith("MAS_ins,") and rows[-1].startswith("Total Runtime,")
+    assert len(rows) == 13 and rows[0].startswith("MAS_ins,") and rows[-2].startswith("Total Runtime,") and rows[-1] == "Fold,plain sums"
 
 
 # ------------------------------------------------------------------------------ two ranks on one GPU (gloo)
@@ -1435,5 +1435,5 @@ def test_cli_runs_resnet50_with_the_fused_classifier(tmp_path, capsys):
         return
     assert [f.name for f in files] == ["gc_2_images.csv"]
     rows = files[0].read_text().strip().splitlines()
-    assert len(rows) == 12 and rows[0].startswith("MAS_ins,") and rows[-2].startswith("Attr Avg Runtime,") and rows[-1].startswith("Total Runtime,")
+    assert len(rows) == 13 and rows[0].startswith("MAS_ins,") and rows[-3].startswith("Attr Avg Runtime,") and rows[-2].startswith("Total Runtime,")
     assert all(np.isfinite(float(r.split(",")[1])) for r in rows)
