@@ -249,3 +249,50 @@ def test_ig_family_random_cases():
         assert rel_inf(got, want) <= 1e-5, (tag, rel_inf(got, want))
     bad = attr.IG(torch.from_numpy(x), model, 10, 3, 1, 0, DEV, torch.tensor(t))
     assert bad == (0, 0, 0, 0)
+
+
+def test_stream_workers_random_batches_bit_identical_to_one_stream(K):
+    """Seeded random batches through the multi-stream drivers: ig_batch (random image count, images per pass -- ragged last pass --,
+    step count, scalar / tensor baseline, IG / Left-IG, buffered / streaming, graphs on / off, 2-4 streams) and rise (random mask
+    count and batch) must equal their one-stream results bit for bit; K16 against sequential fp32 sums.  (Deterministic solvers,
+    conftest.)"""
+    from xai_engine.ig import ig_batch
+    from xai_engine.rise import rise, draw_masks
+    from conftest import load_golden
+    from helpers import tiny_from
+    g = load_golden("ig_small.npz")
+    model = tiny_from(g, DEV)
+    rng = np.random.default_rng(11)
+    for case in range(6 * SCALE):
+        B = int(rng.integers(1, 9))
+        ipp = int(rng.integers(1, 4))
+        steps = int(rng.choice([10, 20, 50]))
+        xs = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(1000 + case)).to(DEV)
+        with torch.no_grad():
+            ts = model(xs).argmax(1)
+        base = (torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(2000 + case)) * 0.3).to(DEV) if rng.random() < 0.4 else float(rng.random())
+        kw = dict(steps=steps, images_per_pass=ipp, baseline=base, want_abs=True)
+        if rng.random() < 0.4:
+            kw["alpha_star"] = 0.9
+        elif rng.random() < 0.5:
+            kw["buffered"] = True
+        one = ig_batch(xs, model, ts, **kw)
+        many = ig_batch(xs, model, ts, streams=int(rng.integers(2, 5)), graphs=bool(rng.random() < 0.7), **kw)
+        for a, b in zip(one, many):
+            assert torch.equal(a, b), (case, B, ipp, steps, kw.keys())
+        n = int(rng.integers(1, 90))
+        bs = int(rng.integers(1, 40))
+        np.random.seed(case)
+        masks = draw_masks((32, 32), n, 4, 0.5)
+        score = lambda b_: torch.softmax(model(b_), 1)[:, 3]                                # noqa: E731
+        r1 = rise(model, xs[:1].cpu(), None, DEV, N=n, s=4, p1=0.5, score_fn=score, batch_size=bs, masks=masks)
+        r3 = rise(model, xs[:1].cpu(), None, DEV, N=n, s=4, p1=0.5, score_fn=score, batch_size=bs, masks=masks, streams=3)
+        assert torch.equal(r1, r3), (case, n, bs)
+        N, P = int(rng.integers(1, 300)), int(rng.integers(1, 700))
+        rows, w = rng.random((N, P)).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+        ws_, ps_ = K.masked_sums(dev(rows), dev(w))
+        aw, ap = np.zeros(P, np.float32), np.zeros(P, np.float32)
+        for i in range(N):
+            aw += rows[i] * w[i]
+            ap += rows[i]
+        assert np.array_equal(ws_.cpu().numpy(), aw / np.float32(N)) and np.array_equal(ps_.cpu().numpy(), ap / np.float32(N)), (case, N, P)
