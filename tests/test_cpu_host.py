@@ -598,3 +598,14 @@ def test_class_quota_replays_the_reference_loop_order():
             used[t] += 1
             want.append((name, t))
         assert q.chosen == want and q.full == (len(want) == count)
+
+
+def test_stream_workers_fail_loudly_without_a_device():
+    """xai_engine.streams on a box without a HIP device: creating a worker raises in the caller (the worker thread reports its
+    boot error instead of dying silently and leaving the caller waiting); backward_turn needs no device to be imported."""
+    from xai_engine import streams
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    with pytest.raises(Exception):
+        streams.workers(torch.device("cuda", 0), 1)
+    assert not streams.on_worker()
