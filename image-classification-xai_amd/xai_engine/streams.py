@@ -42,6 +42,7 @@ _WORKERS_LOCK = threading.Lock()
 _TURN = {}               # device index -> _Turn
 _TURN_LOCK = threading.Lock()
 _local = threading.local()
+_COLD_LOCK = threading.Lock()        # one cold start (`first_alone`) at a time in the process
 CAPTURE_LOCK = threading.Lock()     # ONE hipGraph capture at a time in the process, whoever captures: two threads inside capture_end crash the runtime
 
 
@@ -119,8 +120,10 @@ def first_alone(worker, kind, fn):
     end to end a 3-stream sweep started that way differs from its own repetitions by 4e-8 ... 9e-7, a 1-stream sweep started cold does
     not differ at all (profiles/r03_exp_cold_start_streams.txt).  Started one after the other, fresh handles settle like the main
     thread's.  -> a future."""
-    fut = worker.submit(fn)
-    if kind is not None and kind not in worker.warm:
+    if kind is None or kind in worker.warm:
+        return worker.submit(fn)
+    with _COLD_LOCK:                                     # two CALLER threads warming two workers at once would be the same concurrent start
+        fut = worker.submit(fn)
         concurrent.futures.wait([fut])
         worker.stream.synchronize()
         worker.warm.add(kind)
